@@ -1,0 +1,276 @@
+"""CPU oracle for the VTP hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32 unless stated) *restatement* of the reference algorithm
+for the path named by BASELINE.json's ``north_star``: ViT trunk (patch-embed, RoPE attention,
+SwiGLU blocks), bottleneck, pixel decoder, CLIP text tower + heads, and the (unshipped) loss heads.
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+
+Rules (task §③):
+  * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+    this module -- the product path (``vtp_amd/``) must never import it and fails loudly when the
+    HIP library is missing;
+  * parity pinning: the restatement is checked (a) against the *real* reference imported from
+    /root/reference in the authoring container (``tests/test_oracle_vs_reference.py``; skipped
+    where the tree is absent) and (b) against golden fixtures generated from the real reference
+    (``tests/golden/*.safetensors`` by ``oracle/make_golden.py``) -- these travel to the GPU box.
+  * the loss heads (L1 reconstruction, CLIP InfoNCE) are NOT in the reference:
+    their parity is **unpinned**; the definitions here follow OpenCLIP's ClipLoss and a plain L1.
+
+The functions operate on a reference-format ``state_dict`` (exact checkpoint keys of
+``VTPModel``, vtp/models/vtp_hf/modeling_vtp.py:51) so the same weights feed the oracle, the real
+reference and the HIP path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------
+# RoPE tables -- vtp/models/layers/embeddings.py:131-195
+# --------------------------------------------------------------------------------------------
+def rope_periods(head_dim: int = 64, base: float = 100.0, dtype=torch.bfloat16) -> Tensor:
+    """periods = base ** (2*arange(D_head/4) / (D_head/2)), computed IN ``dtype`` (bf16 by default,
+    vision_transformer.py:74).  embeddings.py:182-195."""
+    return base ** (2 * torch.arange(head_dim // 4, dtype=dtype) / (head_dim // 2))
+
+
+def rope_table(H: int, W: int, periods: Tensor) -> Tuple[Tensor, Tensor]:
+    """(sin, cos), each [H*W, D_head], in periods.dtype -- 'separate' coordinate normalisation,
+    no train-time augmentation.  embeddings.py:131-180 (exact op order, so bf16 rounding matches)."""
+    dd = {"dtype": periods.dtype}
+    coords_h = torch.arange(0.5, H, **dd) / H
+    coords_w = torch.arange(0.5, W, **dd) / W
+    coords = torch.stack(torch.meshgrid(coords_h, coords_w, indexing="ij"), dim=-1)
+    coords = coords.flatten(0, 1)
+    coords = 2.0 * coords - 1.0
+    angles = 2 * math.pi * coords[:, :, None] / periods[None, None, :]
+    angles = angles.flatten(1, 2)
+    angles = angles.tile(2)
+    return torch.sin(angles), torch.cos(angles)
+
+
+def rope_rotate_half(x: Tensor) -> Tensor:
+    """attention.py:12-16."""
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat([-x2, x1], dim=-1)
+
+
+def apply_rope(q: Tensor, k: Tensor, sin: Tensor, cos: Tensor) -> Tuple[Tensor, Tensor]:
+    """attention.py:70-89.  q,k: [B,h,N,d].  All arithmetic in sin.dtype (bf16): q and k -- *including
+    the un-rotated prefix (cls) rows* -- are rounded to bf16 and cast back."""
+    qd, kd, rd = q.dtype, k.dtype, sin.dtype
+    q = q.to(rd)
+    k = k.to(rd)
+    prefix = q.shape[-2] - sin.shape[-2]
+    assert prefix >= 0
+
+    def rot(x):
+        return (x * cos) + (rope_rotate_half(x) * sin)  # attention.py:19-23
+
+    q = torch.cat((q[:, :, :prefix], rot(q[:, :, prefix:])), dim=-2)
+    k = torch.cat((k[:, :, :prefix], rot(k[:, :, prefix:])), dim=-2)
+    return q.to(qd), k.to(kd)
+
+
+# --------------------------------------------------------------------------------------------
+# norms -- vtp/models/layers/normalization.py
+# --------------------------------------------------------------------------------------------
+def rmsnorm(x: Tensor, w: Tensor, eps: float = 1e-5) -> Tensor:
+    """normalization.py:17-22."""
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).type_as(x) * w
+
+
+def layernorm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    """nn.LayerNorm(eps=1e-6) for the decoder (vision_transformer.py:30-34); eps=1e-5 for the text
+    tower (normalization.py:25-31, nn.LayerNorm default)."""
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# --------------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------------
+def self_attention(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int,
+                   rope: Optional[Tuple[Tensor, Tensor]]) -> Tensor:
+    """SelfAttention.forward / compute_attention -- attention.py:91-96,110-126."""
+    B, N, C = x.shape
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, num_heads, C // num_heads)
+    q, k, v = torch.unbind(qkv, 2)
+    q, k, v = [t.transpose(1, 2) for t in (q, k, v)]
+    if rope is not None:
+        q, k = apply_rope(q, k, rope[0], rope[1])
+    o = F.scaled_dot_product_attention(q, k, v)  # scale 1/sqrt(d), no mask  (attention.py:124)
+    o = o.transpose(1, 2).reshape(B, N, C)
+    return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def swiglu_ffn(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
+    """SwiGLUFFN.forward -- ffn.py:77-81."""
+    x1 = F.linear(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"])
+    x2 = F.linear(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"])
+    return F.linear(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
+
+
+def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, norm: str) -> Tensor:
+    """SelfAttentionBlock eval / drop_ratio==0 branch -- block.py:290-296 (LayerScale is Identity
+    unless init_values, block.py:173,185)."""
+    def nrm(t, name):
+        if norm == "rmsnorm":
+            return rmsnorm(t, sd[pre + name + ".weight"], 1e-5)
+        return layernorm(t, sd[pre + name + ".weight"], sd[pre + name + ".bias"], 1e-6)
+
+    x = x + self_attention(nrm(x, "norm1"), sd, pre + "attn.", num_heads, rope)
+    x = x + swiglu_ffn(nrm(x, "norm2"), sd, pre + "mlp.")
+    return x
+
+
+def _depth(sd: Dict[str, Tensor], pre: str) -> int:
+    n = 0
+    while f"{pre}{n}.norm1.weight" in sd or f"{pre}{n}.ln_1.weight" in sd:
+        n += 1
+    return n
+
+
+# --------------------------------------------------------------------------------------------
+# trunk -- vtp/models/encoders/vision_transformer.py + vision_transformer_bottleneck.py
+# --------------------------------------------------------------------------------------------
+def patch_embed(img: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """PatchEmbed.forward -- embeddings.py:61-70: conv k=s=16 -> [B, h*w, D] token order (y, x)."""
+    x = F.conv2d(img, w, b, stride=w.shape[-1])
+    return x.flatten(2).transpose(1, 2)
+
+
+def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottleneck: bool = True,
+                  masks: Optional[Tensor] = None, pre: str = "trunk.") -> Dict[str, Tensor]:
+    """DinoVisionTransformerWithBottleneck.forward(is_training=True) for ONE resolution --
+    vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79."""
+    x = patch_embed(img, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
+    B, hw, D = x.shape
+    H, W = img.shape[-2] // 16, img.shape[-1] // 16
+    if masks is not None:  # vision_transformer.py:194-196
+        x = torch.where(masks.unsqueeze(-1), sd[pre + "mask_token"].to(x.dtype).unsqueeze(0), x)
+        cls = sd[pre + "cls_token"]
+    else:
+        cls = sd[pre + "cls_token"] + 0 * sd[pre + "mask_token"]  # :198
+    x = torch.cat([cls.expand(B, -1, -1), x], dim=1)  # :210-217 (no storage tokens)
+    rope = rope_table(H, W, sd[pre + "rope_embed.periods"])
+    for i in range(_depth(sd, pre + "blocks.")):
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm")
+    xn = rmsnorm(x, sd[pre + "norm.weight"], 1e-5)  # :246
+    cls_t, patch_t = xn[:, 0], xn[:, 1:]
+    if use_bottleneck and (pre + "feature_bottleneck.weight") in sd:  # bottleneck.py:66-79
+        wb = sd[pre + "feature_bottleneck.weight"]
+        cls_t = F.linear(cls_t, wb)
+        patch_t = F.linear(patch_t.reshape(-1, D), wb).reshape(B, hw, -1)
+    return {"x_norm_clstoken": cls_t, "x_norm_patchtokens": patch_t, "x_prenorm": x}
+
+
+def reconstruction_latents(sd, img, num_heads) -> Tensor:
+    """VTPModel.get_reconstruction_latents -- modeling_vtp.py:337-360,379-395."""
+    out = trunk_forward(sd, img, num_heads, use_bottleneck=True)
+    pt = out["x_norm_patchtokens"]
+    B, N, C = pt.shape
+    return pt.transpose(1, 2).reshape(B, C, img.shape[-2] // 16, img.shape[-1] // 16)
+
+
+# --------------------------------------------------------------------------------------------
+# pixel decoder -- vtp/models/decoders/pixel_decoder.py:134-162
+# --------------------------------------------------------------------------------------------
+def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.") -> Tensor:
+    B, _, H, W = latents.shape
+    x = F.conv2d(latents, sd[pre + "proj_in.weight"], sd[pre + "proj_in.bias"])  # :138
+    D = x.shape[1]
+    x = x.flatten(2).transpose(1, 2)  # :141
+    rope = rope_table(H, W, sd[pre + "rope_embed.periods"])  # :144
+    for i in range(_depth(sd, pre + "blocks.")):
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm")
+    x = layernorm(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-6)  # :151
+    x = x.transpose(1, 2).reshape(B, D, H, W)  # :154
+    x = F.conv2d(x, sd[pre + "proj_out.weight"], sd[pre + "proj_out.bias"])  # :157
+    return F.pixel_shuffle(x, 16)  # :160
+
+
+# --------------------------------------------------------------------------------------------
+# CLIP text tower + heads -- vtp/models/encoders/text_transformer.py, modeling_vtp.py:244-333
+# --------------------------------------------------------------------------------------------
+def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True) -> Tensor:
+    """ResidualAttentionBlock.forward -- block.py:416-427 with nn.MultiheadAttention (packed
+    in_proj, additive causal mask text_transformer.py:334-338) and exact-erf GELU MLP."""
+    B, T, C = x.shape
+    h = layernorm(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], 1e-5)
+    qkv = F.linear(h, sd[pre + "attn.in_proj_weight"], sd[pre + "attn.in_proj_bias"])
+    q, k, v = qkv.reshape(B, T, 3, num_heads, C // num_heads).unbind(2)
+    q, k, v = [t.transpose(1, 2) for t in (q, k, v)]
+    o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+    o = o.transpose(1, 2).reshape(B, T, C)
+    x = x + F.linear(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
+    h = layernorm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], 1e-5)
+    h = F.gelu(F.linear(h, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"]))
+    return x + F.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+
+
+def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True) -> Tensor:
+    """VTPModel.get_clip_text_feature -- modeling_vtp.py:278-310; argmax (EOT) pooling
+    text_transformer.py:213-228."""
+    x = F.embedding(text, sd["token_embedding.weight"]) + sd["positional_embedding"]
+    for i in range(_depth(sd, "text_transformer.resblocks.")):
+        x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads)
+    x = layernorm(x, sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
+    x = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
+    x = x @ sd["text_projection"]
+    return F.normalize(x, dim=-1) if normalize else x
+
+
+def clip_image_feature(sd, img: Tensor, num_heads: int, normalize: bool = True) -> Tensor:
+    """VTPModel.get_clip_image_feature -- modeling_vtp.py:244-276 with the defaults
+    vision_bottleneck_ae_only=True (=> no bottleneck) and vision_clip_feat='cls'."""
+    out = trunk_forward(sd, img, num_heads, use_bottleneck=False)
+    f = F.linear(out["x_norm_clstoken"], sd["visual_proj.weight"])
+    return F.normalize(f, dim=-1) if normalize else f
+
+
+def clip_logits(sd, img, text, vis_heads, txt_heads) -> Tensor:
+    """VTPModel.get_clip_logits -- modeling_vtp.py:312-333."""
+    i = clip_image_feature(sd, img, vis_heads)
+    t = clip_text_feature(sd, text, txt_heads)
+    return sd["logit_scale"].exp() * i @ t.T
+
+
+# --------------------------------------------------------------------------------------------
+# loss heads -- NOT in the reference (parity unpinned)
+# --------------------------------------------------------------------------------------------
+def l1_loss(rec: Tensor, target: Tensor) -> Tensor:
+    return (rec.float() - target.float()).abs().mean()
+
+
+def clip_loss(img_f: Tensor, txt_f: Tensor, logit_scale_exp: Tensor) -> Tensor:
+    """OpenCLIP ClipLoss (single process): 0.5*(CE(s*I*T^T) + CE(s*T*I^T)), labels=arange."""
+    logits = logit_scale_exp * img_f @ txt_f.T
+    labels = torch.arange(logits.shape[0])
+    return 0.5 * (F.cross_entropy(logits, labels) + F.cross_entropy(logits.T, labels))
+
+
+def rec_train_loss(sd, img, vis_heads, dec_heads) -> Tensor:
+    """forward_type='rec' (vtp.py:487-512 / modeling_vtp.py:440-455) + L1."""
+    lat = reconstruction_latents(sd, img, vis_heads)
+    rec = decoder_forward(sd, lat, dec_heads)
+    return l1_loss(rec, img)
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, b1: float, b2: float,
+               eps: float, wd: float) -> None:
+    """torch.optim.AdamW semantics (decoupled weight decay), in place, fp32."""
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
