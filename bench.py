@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- VTP training-step throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimizer step of the hot path on one batch of synthetic 256x256 images already resident in HBM
+(forward, loss, backward, gradient all-reduce, fused AdamW, bf16 weight refresh).  Default workload: VTP-Base f16d64,
+32 images per GPU (BASELINE config 3's per-GPU shard; weak scaling), reconstruction (L1) objective -- the part of the
+config-3 step that is built so far (config.workload says exactly what ran).  Rank 0 prints ONE JSON line.
+
+Also reported on the same line:
+  roofline     -- the dominant kernel (gemm_nt bf16 MFMA GEMM): algorithmic FLOPs (2*M*N*K per launch) / average launch
+                  duration measured with HIP events on the launch stream over one instrumented step run right after
+                  the timed region (kept out of it so event overhead cannot inflate `value`); peak = 2.5 PFLOP/s dense
+                  bf16 (MI355X_MICROARCH.md).  `step_frac` is the whole-step figure of BASELINE.md §4
+                  (images/s/GPU x GFLOP/image / 2.5e6).
+  cpu_baseline -- the CPU oracle (oracle/vtp_oracle.py, kind "port": a PyTorch-fp32 restatement of the reference, which
+                  is itself PyTorch) running the same train step on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+
+WORKLOADS = {
+    # name: (config kwargs, per-GPU batch, resolution)
+    "vtp_base_rec": (dict(), 32, 256),
+    "vtp_small_rec": (dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_embed_dim=384, text_depth=12,
+                           text_num_heads=6, decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6), 64, 256),
+}
+
+
+def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
+    """BASELINE.md §4 / SURVEY.md §8d algorithmic FLOPs of one forward, per image."""
+    f = L * (2 * N * (4 * D * D + 3 * D * H) + 4 * N * N * D)
+    if enc:
+        f += 2 * hw * 768 * D + 2 * N * D * 64
+    else:
+        f += 2 * hw * 64 * D + 2 * hw * D * 768
+    return f / 1e9
+
+
+def cpu_baseline(model, B_cpu, res, budget_s=20.0):
+    """The CPU oracle timed on the host: same rec train step (fwd + L1 + autograd bwd + AdamW), fp32, all cores."""
+    from oracle import vtp_oracle as O
+    cfg = model.config
+    sd = {k: v.detach().float().cpu().clone() if v.dtype == torch.float32 else v.detach().cpu().clone()
+          for k, v in model.state_dict().items()}
+    keys = [k for k in sd if (k.startswith("trunk.") or k.startswith("pixel_decoder.")) and sd[k].dtype == torch.float32]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    opt = torch.optim.AdamW([sd[k] for k in keys], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    img = torch.randn(B_cpu, 3, res, res, generator=torch.Generator().manual_seed(99))
+    n_thr = torch.get_num_threads()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = O.rec_train_loss(sd, img, cfg.vision_num_heads, cfg.decoder_num_heads)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 10:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * B_cpu / dt, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(),
+            "kind": "port", "sample": f"{n} fp32 train steps (fwd+L1+bwd+AdamW) of the same model at batch {B_cpu} after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="vtp_base_rec", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vtp_amd import VTPConfig, VTPModel, VTPTrainer, ops
+    cfg_kw, B, res = WORKLOADS[args.workload]
+    B = args.batch or B
+    torch.manual_seed(0)
+    model = VTPModel(VTPConfig(**cfg_kw)).to(dev)
+    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step_rec(img)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step_rec(img)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+
+    # ---- dominant-kernel roofline: one instrumented step, HIP events around every gemm_nt launch (rank 0)
+    roof = None
+    if rank == 0:
+        recs = []
+        orig = ops.gemm_nt
+
+        def timed_gemm(a, b, c, **kw):
+            M = kw.get("M") if kw.get("M") is not None else a.shape[0]
+            K = kw.get("K") if kw.get("K") is not None else a.shape[1]
+            N = kw.get("N") if kw.get("N") is not None else b.shape[0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(a, b, c, **kw)
+            e1.record()
+            recs.append((2.0 * M * N * K, e0, e1))
+
+        import vtp_amd.engine as eng
+        ops.gemm_nt = timed_gemm
+        try:
+            trainer.step_rec(img)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_nt = orig
+        assert eng.ops.gemm_nt is orig
+        fl = sum(r[0] for r in recs)
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "vtp::gemm_nt_kernel<128,128,*> (bf16 MFMA 32x32x16, all epilogues)",
+                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches_per_step": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
+                "gemm_ms_per_step": round(ms, 3), "flop_per_launch_avg": fl / len(recs)}
+    if world > 1:
+        sync()
+
+    c = model.config
+    hw = (res // 16) ** 2
+    from vtp_amd.config import swiglu_hidden
+    enc = vit_fwd_gflop(c.vision_embed_dim, swiglu_hidden(c.vision_embed_dim), c.vision_depth, hw + 1, hw, True)
+    dec = vit_fwd_gflop(c.decoder_embed_dim, swiglu_hidden(c.decoder_embed_dim), c.decoder_depth, hw, hw, False)
+    gflop_img = 3.0 * (enc + dec)
+    ips = world * B * args.steps / elapsed
+    out = {
+        "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload == "vtp_base_rec"
+        else "images/sec/node VTP-S f16d64 256x256 train step",
+        "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: full optimizer step (fwd + L1 recon loss + bwd + grad all-reduce + AdamW) "
+                               f"of VTPModel trunk+pixel_decoder, {B} img/GPU @ {res}x{res}, random-init weights; "
+                               "contrastive + SSL heads of config 3 not yet in the step",
+                   "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
+                   "train_gflop_per_image": round(gflop_img, 1)},
+        "loss": round(loss_val, 5),
+        "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
+        "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+    if rank == 0:
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/* vtp_hip.h -- C ABI of libvtp_hip.so: the MI355X (gfx950 / CDNA4) kernels of the VTP training hot path.
+ *
+ * The reference (MiniMax-AI/VTP) is pure PyTorch: it has no FFI / plugin registry, every device
+ * "kernel" is an ATen call issued from an nn.Module.forward.  Each entry point below
+ * therefore names the reference ATen call site(s) (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless stated; bf16 = raw uint16
+ *     storage (IEEE bfloat16, round-to-nearest-even); "f32" = float.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are enqueued
+ *     asynchronously; nothing synchronises the device.
+ *   - return 0 on success, VTP_ERR_ARG (-1) on a rejected argument (message via vtp_last_error()),
+ *     or a positive hipError_t if the launch failed.  The library never aborts the process.
+ *   - no hidden global state apart from the last-error string (thread-local) and kernel attributes;
+ *     callers own every buffer (ownership never transfers).
+ *   - token matrices are row-major [rows, features] with an explicit leading dimension where given.
+ */
+#ifndef VTP_HIP_H
+#define VTP_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTP_ABI_VERSION 1
+
+int vtp_abi_version(void);
+const char* vtp_last_error(void);
+
+/* ---- GEMM ------------------------------------------------------------------------------------
+ * C[M,N] = epilogue(alpha * A[M,K] * B[N,K]^T).  A, B bf16 K-contiguous.  Replaces every nn.Linear /
+ * 1x1-conv / patch-embed conv `addmm`: attention.py:92,94 (qkv, proj), ffn.py:78-81 (w1,w2,w3),
+ * vision_transformer_bottleneck.py:68-74, pixel_decoder.py:138,157, embeddings.py:64 (after im2col),
+ * block.py:412-414 + nn.MultiheadAttention in/out proj (text tower), modeling_vtp.py:274,306, and (with
+ * transposed operands) their autograd dgrad/wgrad.
+ *   a_grp/a_pre, c_grp/c_pre: optional row remap row(m) = m + (m / grp + 1) * pre (grp = 0: none) used to
+ *   read/write only the patch rows of a [B, 1+hw, D] token stream.  c_grp = -1 selects the SwiGLU de-interleave
+ *   row(m) = ((m>>4)<<3) + (m&7) + ((m&8) ? c_pre : 0) (wgrad of the interleaved [w1|w2] matrix, c_pre = H).
+ * Epilogues:
+ *   VTP_EPI_BF16        C bf16 = acc + bias
+ *   VTP_EPI_F32         C f32  = resid + gamma * (acc + bias)            (bias/gamma/resid optional; block.py:293-294)
+ *   VTP_EPI_SWIGLU      B rows interleaved [8 x w1 | 8 x w2] per 16; C bf16 [M, N/2] = silu(x1) * x2, C2 bf16 [M,N] = (x1|x2)
+ *   VTP_EPI_GELU        C bf16 = gelu_erf(acc + bias), C2 bf16 = acc + bias (optional)
+ *   VTP_EPI_F32_ATOMIC  C f32 += alpha * acc, split-K over `splits` slices (wgrad)
+ */
+enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4 };
+int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
+                const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
+                int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------
+ * kind 0 = RMSNorm (normalization.py:17-22, eps 1e-5, no bias), 1 = LayerNorm (vision_transformer.py:30-34
+ * eps 1e-6 decoder; normalization.py:25-31 text).  x f32 [M, D] -> y bf16 [M, D]; stats f32 [M,2] = (mean, rstd).
+ * bwd: dx f32 [M,D] = (dres ? dres : 0) + norm_bwd(dy bf16), optionally also written as bf16 (dx_bf16, the A operand
+ * of the next dgrad GEMM); dw/db f32 [D] are ACCUMULATED (+=) atomically. */
+int vtp_norm_fwd(const float* x, const float* w, const float* b, void* y, float* stats, int M, int D, float eps,
+                 int kind, void* stream);
+int vtp_norm_bwd(const void* dy, const float* x, const float* w, const float* stats, const float* dres, float* dx,
+                 void* dx_bf16, float* dw, float* db, int M, int D, int kind, void* stream);
+
+/* ---- RoPE (attention.py:12-23,70-89) ----------------------------------------------------------
+ * In place on the q and k thirds of a packed qkv bf16 [B*N, 3*D] buffer (head h at column h*64 of each third).
+ * Rows n < prefix (cls) are untouched; sin/cos are the reference's bf16 tables [N-prefix, 64].  Rounding follows
+ * eager bf16: bf16(bf16(x*cos) + bf16(rot(x)*sin)).  inverse != 0 applies the transpose (backward). */
+int vtp_rope_qk(void* qkv, const void* sin, const void* cos, int B, int N, int heads, int prefix, int inverse,
+                void* stream);
+
+/* ---- attention (attention.py:124 F.scaled_dot_product_attention; text: nn.MultiheadAttention causal) ----
+ * q/k/v/o are bf16 with element strides: batch stride `sb`, token stride `sn`, head h at +h*64 (head_dim is 64).
+ * lse f32 [B, heads, N] (natural-log-sum-exp of scale*q.k).  causal != 0 masks key > query. */
+int vtp_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int N, int heads,
+                 long sb_qkv, long sn_qkv, long sb_o, long sn_o, float scale, int causal, void* stream);
+int vtp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                 float* delta /* scratch f32 [B,heads,N] */, void* dq, void* dk, void* dv, int B, int N, int heads,
+                 long sb_qkv, long sn_qkv, long sb_o, long sn_o, float scale, int causal, void* stream);
+
+/* ---- data movement / elementwise --------------------------------------------------------------- */
+/* im2col for the 16x16/s16 patch-embed conv (embeddings.py:58,64-69): img f32 [B,3,H,W] -> patches bf16 [B*h*w, 768],
+ * K order (c, ky, kx), token order (y, x). */
+int vtp_im2col16(const float* img, void* patches, int B, int H, int W, void* stream);
+/* col2im adjoint is not needed: the image is data (no input gradient). */
+
+/* rows [B, N, D] f32: write row 0 of every batch element = cls[D] (vision_transformer.py:198,210-217);
+ * optionally substitute mask_token on masked patch rows (vision_transformer.py:195). masks: uint8 [B, N-1] or NULL. */
+int vtp_assemble_tokens(float* x, const float* cls, const float* mask_token, const unsigned char* masks, int B, int N,
+                        int D, void* stream);
+
+/* out[c, r] = in[r, c] for a bf16 [R, C] matrix (ld_in) -> [C, ld_out]; columns r in [R, ld_out) are zero-filled.
+ * If colsum != NULL, colsum[c'] += sum_r in[r,c] (bias gradients); c' = c, or, when colsum_swiglu_h = H > 0, the
+ * de-interleaved SwiGLU index ((c>>4)<<3) + (c&7) + ((c&8) ? H : 0)  (b1 then b2, each [H]).
+ * in_grp/in_pre: input row remap row(r) = r + (r / in_grp + 1) * in_pre (in_grp = 0: none), as in vtp_gemm_nt. */
+int vtp_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, float* colsum, int colsum_swiglu_h, int in_grp,
+                       int in_pre, int R, int C, void* stream);
+/* out[d] += sum_b in[b*stride + d], f32 (gradient of the broadcast cls token, vision_transformer.py:210-217). */
+int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream);
+
+/* f32 -> bf16 cast (n elements); f32 [R,C] -> bf16 transposed [C,R] (weight caches W, W^T). */
+int vtp_cast_f32_bf16(const float* in, void* out, long n, void* stream);
+int vtp_cast_transpose_f32_bf16(const float* in, void* out, int R, int C, void* stream);
+/* Batched refresh of the bf16 compute copies of all fp32 master weights in ONE launch.  `descs` is a device array of
+ * n records of 8 x int64: {src f32*, src2 f32*, dst, dstT, R, C, mode, tile_start}; mode 0: dst bf16 [R,C] = src,
+ * dstT bf16 [C,R] = src^T (either may be NULL); mode 1: the logical matrix is the SwiGLU interleave of src=w1 and
+ * src2=w2 (16-row groups = [8 rows w1 | 8 rows w2], R = 2H); mode 2: dst f32 [R] = interleave of two bias vectors.
+ * tile_start = exclusive prefix sum of per-record tile counts (64x64 tiles; mode 2: 256 elements per tile). */
+int vtp_prep_weights(const void* descs, int n, int total_tiles, void* stream);
+
+/* SwiGLU backward (ffn.py:80): given dh bf16 [M,H] and saved x12 bf16 [M,2H] (interleaved 8|8), writes dx12 bf16 [M,2H]. */
+int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, int M, int H, void* stream);
+/* GELU backward (text MLP, block.py:399): dx = dy * gelu'(pre). */
+int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream);
+
+/* PixelShuffle(16) (pixel_decoder.py:160): t bf16 [B*h*w, 768] token-major -> img f32 [B,3,16h,16w]. */
+int vtp_pixel_shuffle16(const void* t, float* img, int B, int h, int w, void* stream);
+/* L1 reconstruction loss on the token-major decoder output: loss_sum[0] += sum |shuffle(t) - target|;
+ * dt bf16 [B*h*w,768] = sign(shuffle(t) - target) * gscale  (gscale = loss_weight / numel). */
+int vtp_l1_loss_fwd_bwd(const void* t, const float* target, void* dt, float* loss_sum, int B, int h, int w,
+                        float gscale, void* stream);
+
+/* fused AdamW over one flat f32 parameter buffer (torch.optim.AdamW semantics); also refreshes the bf16 copy. */
+int vtp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
+int vtp_ema(float* t, const float* s, long n, float momentum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,110 @@
+"""CPU tests of the host-side logic: config mirror, checkpoint-key contract, flat-parameter ordering, RoPE tables,
+gradient bucketing ranges, and the world_size-2 gloo path of the bucketed all-reduce."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_defaults_are_vtp_base_and_validation():
+    from vtp_amd.config import VTPConfig, swiglu_hidden
+    c = VTPConfig()
+    assert (c.vision_embed_dim, c.vision_depth, c.vision_num_heads) == (768, 12, 12)
+    assert c.vision_feature_bottleneck == 64 and c.decoder_norm_layer == "layernorm" and c.vision_norm_layer == "rmsnorm"
+    assert swiglu_hidden(768) == 2048 and swiglu_hidden(384) == 1024 and swiglu_hidden(1024) == 2736 and swiglu_hidden(128) == 344
+    with pytest.raises(ValueError, match="head_dim"):
+        VTPConfig(vision_embed_dim=768, vision_num_heads=8)
+    with pytest.raises(ValueError, match="vision_clip_feat"):
+        VTPConfig(vision_clip_feat="bogus")
+    d = c.to_dict()
+    assert d["model_type"] == "vtp" and VTPConfig.from_dict(d).to_dict() == d
+
+
+def test_state_dict_contract_matches_reference_checkpoint(golden_sd):
+    """Exact key names, shapes and dtypes of a reference VTPModel checkpoint."""
+    from oracle.ref_stubs import TINY
+    from vtp_amd import VTPConfig, VTPModel
+    m = VTPModel(VTPConfig(**TINY))
+    sd = m.state_dict()
+    assert list(sd.keys()) != [] and set(sd.keys()) == set(golden_sd.keys())
+    for k, v in sd.items():
+        assert v.shape == golden_sd[k].shape and v.dtype == golden_sd[k].dtype, k
+    m.load_state_dict(golden_sd, strict=True)
+    assert torch.equal(m.trunk.rope_embed.periods, golden_sd["trunk.rope_embed.periods"])
+
+
+def test_reference_checkpoint_directory_loads(tmp_path, golden_sd):
+    """A directory written in the reference's HF layout (config.json + model.safetensors) loads unchanged."""
+    import json
+    from safetensors.torch import save_file
+    from oracle.ref_stubs import TINY
+    from vtp_amd import VTPModel
+    cfg = dict(TINY, model_type="vtp", architectures=["VTPModel"], transformers_version="5.15.0")
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in golden_sd.items()}, str(tmp_path / "model.safetensors"))
+    m = VTPModel.from_pretrained(str(tmp_path))
+    assert torch.equal(m.state_dict()["pixel_decoder.proj_out.weight"], golden_sd["pixel_decoder.proj_out.weight"])
+
+
+def test_flat_order_keeps_swiglu_pairs_adjacent():
+    from vtp_amd.engine import _flat_order
+    names = ["a.norm1.weight", "a.mlp.w1.weight", "a.mlp.w1.bias", "a.mlp.w2.weight", "a.mlp.w2.bias", "a.mlp.w3.weight"]
+    assert _flat_order(names) == ["a.norm1.weight", "a.mlp.w1.weight", "a.mlp.w2.weight", "a.mlp.w1.bias", "a.mlp.w2.bias",
+                                  "a.mlp.w3.weight"]
+
+
+def test_rope_tables_match_oracle():
+    from oracle import vtp_oracle as O
+    from vtp_amd.engine import rope_tables
+    per = O.rope_periods(64)
+    for H, W in [(16, 16), (6, 10), (32, 32)]:
+        s, c = rope_tables(per, H, W, "cpu")
+        so, co = O.rope_table(H, W, per)
+        assert torch.equal(s, so) and torch.equal(c, co)
+
+
+def test_range_helpers():
+    from vtp_amd.train import merge_ranges, param_ranges
+    assert merge_ranges([(8, 12), (0, 4), (4, 8), (20, 24)]) == [(0, 12), (20, 24)]
+    offs = {"trunk.a": (0, 6), "visual_proj.weight": (8, 4), "pixel_decoder.b": (12, 8), "text.c": (20, 3)}
+    assert param_ranges(offs, ("trunk.", "pixel_decoder.")) == [(0, 8), (12, 20)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vtp_amd.train import GradBucketer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    flat = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    gb = GradBucketer(flat)
+    gb.reduce_range(4, 16)   # bucket launched "during backward"
+    gb.reduce_range(24, 40)
+    gb.wait()
+    out[rank] = flat.clone()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    base = torch.arange(40, dtype=torch.float32)
+    for r in range(world):
+        exp = base * (r + 1)
+        exp[4:16] = base[4:16] * 3   # sum over ranks of (rank+1)
+        exp[24:40] = base[24:40] * 3
+        assert torch.equal(out[r], exp)

@@ -1,0 +1,62 @@
+"""ctypes binding of libvtp_hip.so (include/vtp_hip.h).  The product path has NO fallback: if the library is
+missing or a call is rejected, a RuntimeError is raised (never a silent eager/CPU path)."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvtp_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_long, c_float
+
+# name -> argtypes (must mirror include/vtp_hip.h exactly; tests/test_abi.py checks the export list)
+SIGNATURES = {
+    "vtp_gemm_nt": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vtp_norm_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "vtp_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],  # dy x w stats dres dx dxb dw db M D kind stream
+    "vtp_rope_qk": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vtp_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],
+    "vtp_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],
+    "vtp_im2col16": [_P, _P, _I, _I, _I, _P],
+    "vtp_assemble_tokens": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_transpose_bf16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],  # in ld out ld colsum swiglu_h in_grp in_pre R C stream
+    "vtp_strided_rowsum": [_P, _L, _P, _I, _I, _P],
+    "vtp_cast_f32_bf16": [_P, _P, _L, _P],
+    "vtp_cast_transpose_f32_bf16": [_P, _P, _I, _I, _P],
+    "vtp_prep_weights": [_P, _I, _I, _P],
+    "vtp_swiglu_bwd": [_P, _P, _P, _I, _I, _P],
+    "vtp_gelu_bwd": [_P, _P, _P, _L, _P],
+    "vtp_pixel_shuffle16": [_P, _P, _I, _I, _I, _P],
+    "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "vtp_adamw": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "vtp_ema": [_P, _P, _L, _F, _P],
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"vtp_amd: {LIB_PATH} not found. The HIP library is mandatory (there is no fallback path): "
+            "run `python -c 'import __graft_entry__ as g; g.build()'` or `python vtp_amd/build.py`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vtp_abi_version.restype = c_int
+    lib.vtp_last_error.restype = c_char_p
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud
+        fn.argtypes = args
+        fn.restype = c_int
+    if lib.vtp_abi_version() != 1:
+        raise RuntimeError("vtp_amd: ABI version mismatch between vtp_amd/_lib.py and libvtp_hip.so")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = _lib.vtp_last_error().decode(errors="replace") if _lib is not None else ""
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

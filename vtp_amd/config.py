@@ -1,0 +1,111 @@
+"""VTPConfig -- field-for-field mirror of the reference configuration
+(vtp/models/vtp_hf/configuration_vtp.py:67-166; defaults = VTP-Base f16d64) so a reference ``config.json`` loads
+unchanged.  Plain Python (no transformers dependency on the hot path)."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+
+class VTPConfig:
+    model_type = "vtp"
+
+    def __init__(
+        self,
+        image_size: int = 256,
+        train_clip: bool = True,
+        train_reconstruction: bool = True,
+        vision_patch_size: int = 16,
+        vision_embed_dim: int = 768,
+        vision_depth: int = 12,
+        vision_num_heads: int = 12,
+        vision_mlp_ratio: float = 4.0,
+        vision_ffn_layer: str = "swiglu",
+        vision_norm_layer: str = "rmsnorm",
+        vision_init_values: Optional[float] = None,
+        vision_use_qk_norm: bool = False,
+        vision_feature_bottleneck: int = 64,
+        vision_bottleneck_ae_only: bool = True,
+        vision_clip_feat: str = "cls",
+        text_context_length: int = 77,
+        text_vocab_size: int = 49408,
+        text_embed_dim: int = 768,
+        text_num_heads: int = 12,
+        text_depth: int = 12,
+        text_mlp_ratio: float = 4.0,
+        text_ls_init_value: Optional[float] = None,
+        text_embed_cls: bool = False,
+        text_pad_id: int = 0,
+        text_no_causal_mask: bool = False,
+        text_pool_type: str = "argmax",
+        text_proj_type: str = "linear",
+        text_proj_bias: bool = False,
+        text_output_tokens: bool = False,
+        text_quick_gelu: bool = False,
+        decoder_embed_dim: int = 768,
+        decoder_num_heads: int = 12,
+        decoder_depth: int = 12,
+        decoder_ffn_layer: str = "swiglu",
+        decoder_norm_layer: str = "layernorm",
+        decoder_init_values: Optional[float] = None,
+        decoder_use_qk_norm: bool = False,
+        init_logit_scale: Optional[float] = None,
+        init_logit_bias: Optional[float] = None,
+        nonscalar_logit_scale: bool = False,
+        **kwargs,
+    ):
+        loc = dict(locals())
+        for k in ("self", "kwargs", "__class__"):
+            loc.pop(k, None)
+        self.__dict__.update(loc)
+        self.extra = dict(kwargs)  # unknown keys of a HF config.json (transformers_version, architectures, ...)
+        self._validate()
+
+    # what the gfx950 kernels implement today; anything else is rejected loudly rather than silently approximated
+    def _validate(self):
+        def need(cond, msg):
+            if not cond:
+                raise ValueError(f"VTPConfig: {msg}")
+
+        need(self.vision_patch_size == 16, "vision_patch_size must be 16 (f16 tokenizer)")
+        for pre in ("vision", "decoder", "text"):
+            d, h = getattr(self, f"{pre}_embed_dim"), getattr(self, f"{pre}_num_heads")
+            need(d % h == 0 and d // h == 64, f"{pre}: head_dim must be 64 (got {d}/{h})")
+        need(self.vision_ffn_layer == "swiglu" and self.decoder_ffn_layer == "swiglu", "only the swiglu FFN is implemented")
+        need(self.vision_norm_layer in ("rmsnorm", "layernorm"), "vision_norm_layer must be rmsnorm|layernorm")
+        need(self.decoder_norm_layer in ("rmsnorm", "layernorm"), "decoder_norm_layer must be rmsnorm|layernorm")
+        need(not self.vision_use_qk_norm and not self.decoder_use_qk_norm, "qk-norm is not implemented")
+        need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
+        need(not self.text_embed_cls and self.text_pool_type == "argmax" and not self.text_no_causal_mask,
+             "text tower: only the causal / argmax-pooled CLIP configuration is implemented")
+        need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
+        need(not self.text_quick_gelu, "quick_gelu is not implemented")
+        need(self.init_logit_bias is None, "SigLIP logit_bias is not implemented")
+
+    def to_dict(self):
+        d = {k: v for k, v in self.__dict__.items() if k != "extra"}
+        d["model_type"] = self.model_type
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        d = dict(d)
+        d.pop("model_type", None)
+        return cls(**d)
+
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as fh:
+            json.dump(self.to_dict(), fh, indent=2)
+
+    @classmethod
+    def from_pretrained(cls, path: str):
+        with open(os.path.join(path, "config.json")) as fh:
+            return cls.from_dict(json.load(fh))
+
+
+def swiglu_hidden(dim: int, ratio: float = 4.0, align_to: int = 8) -> int:
+    """SwiGLUFFN hidden width -- ffn.py:71-72 (with mlp_hidden_dim = int(dim*ffn_ratio), block.py:176)."""
+    d = int(int(dim * ratio) * 2 / 3)
+    return d + (-d % align_to)

@@ -1,0 +1,189 @@
+// RMSNorm / LayerNorm forward + backward for the fp32 residual stream (HBM-bound, one wave per row).
+//   fwd:  y(bf16) = norm(x f32) * w (+ b);  stats[m] = (mean, rstd)    [normalization.py:17-22, nn.LayerNorm]
+//   bwd:  dx f32 = dres + d(norm)/dx ;  dw/db accumulated with one atomicAdd per column per workgroup.
+// Rows are read as float4 per lane (16 B), row-resident in registers (D <= 2048).
+#include "common.h"
+#include "vtp_hip.h"
+
+namespace vtp {
+
+constexpr int NORM_MAXC = 8;  // float4 chunks per lane -> D <= 8*64*4 = 2048 (template NC = ceil(D/256))
+
+template <int KIND, int NC>  // KIND 0 rms, 1 layernorm; NC float4 chunks per lane
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, bf16* __restrict__ y,
+                                                       float* __restrict__ stats, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  f32x4 v[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < D) {
+      v[c] = *(const f32x4*)(xr + col);
+      s += (KIND == 0) ? (v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3])
+                       : (v[c][0] + v[c][1] + v[c][2] + v[c][3]);
+    }
+  }
+  s = wave_sum(s);
+  float mean = 0.f, rstd;
+  if (KIND == 0) {
+    rstd = rsqrtf(s / D + eps);
+  } else {
+    mean = s / D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[c][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    q = wave_sum(q);
+    rstd = rsqrtf(q / D + eps);
+  }
+  bf16* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < D) {
+      f32x4 wv = *(const f32x4*)(w + col);
+      f32x4 o;
+      if (KIND == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[c][e] * rstd * wv[e];
+      } else {
+        f32x4 bv = *(const f32x4*)(b + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * wv[e] + bv[e];
+      }
+      *(bf16x4*)(yr + col) = __builtin_convertvector(o, bf16x4);
+    }
+  }
+  if (lane == 0 && stats) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+template <int KIND, int NC>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ w, const float* __restrict__ stats,
+                                                       const float* __restrict__ dres, float* __restrict__ dx,
+                                                       bf16* __restrict__ dxb, float* __restrict__ dw, float* __restrict__ db, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wv_id = threadIdx.x >> 6;
+  f32x4 wreg[NC], dwacc[NC], dbacc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < D) wreg[c] = *(const f32x4*)(w + col);
+    dwacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dbacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wv_id; row < M; row += gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + (size_t)row * D;
+    const bf16* gr = dy + (size_t)row * D;
+    f32x4 xh[NC], g[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < D) {
+        f32x4 xv = *(const f32x4*)(xr + col);
+        f32x4 gy = __builtin_convertvector(*(const bf16x4*)(gr + col), f32x4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[c][e] = (xv[e] - mean) * rstd;
+          g[c][e] = gy[e] * wreg[c][e];
+          s1 += g[c][e];
+          s2 += g[c][e] * xh[c][e];
+          dwacc[c][e] += gy[e] * xh[c][e];
+          dbacc[c][e] += gy[e];
+        }
+      }
+    }
+    s2 = wave_sum(s2) / D;
+    if (KIND == 1) s1 = wave_sum(s1) / D; else s1 = 0.f;
+    float* dxr = dx + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
+        if (dres) {
+          f32x4 r = *(const f32x4*)(dres + (size_t)row * D + col);
+          o += r;
+        }
+        *(f32x4*)(dxr + col) = o;
+        if (dxb) *(bf16x4*)(dxb + (size_t)row * D + col) = __builtin_convertvector(o, bf16x4);
+      }
+    }
+  }
+  // reduce dw/db over the 4 waves of the block through LDS, then one atomic per column
+  __shared__ float red[4][NC * 256];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && (KIND == 0 || db == nullptr)) break;
+    if (pass == 0 && dw == nullptr) continue;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wv_id][(c * 64 + lane) * 4 + e] = pass == 0 ? dwacc[c][e] : dbacc[c][e];
+    __syncthreads();
+    float* out = pass == 0 ? dw : db;
+    for (int col = threadIdx.x; col < D; col += 256)
+      unsafeAtomicAdd(out + col, red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+  }
+}
+
+}  // namespace vtp
+using namespace vtp;
+
+#define NORM_DISPATCH(KERNEL, KIND, ...)                                                            \
+  do {                                                                                              \
+    const int nc = cdiv(D, 256);                                                                    \
+    if (nc <= 1) hipLaunchKernelGGL((KERNEL<KIND, 1>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);      \
+    else if (nc == 2) hipLaunchKernelGGL((KERNEL<KIND, 2>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+    else if (nc == 3) hipLaunchKernelGGL((KERNEL<KIND, 3>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+    else if (nc == 4) hipLaunchKernelGGL((KERNEL<KIND, 4>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<KIND, 8>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);              \
+  } while (0)
+
+extern "C" int vtp_norm_fwd(const float* x, const float* w, const float* b, void* y, float* stats, int M, int D,
+                            float eps, int kind, void* stream) {
+  VTP_REQUIRE(x && w && y, "vtp_norm_fwd: null pointer");
+  VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_fwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  VTP_REQUIRE(kind == 0 || (kind == 1 && b), "vtp_norm_fwd: kind must be 0 (rms) or 1 (layernorm, needs bias)");
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (kind == 0)
+    NORM_DISPATCH(norm_fwd_kernel, 0, x, w, b, (bf16*)y, stats, M, D, eps);
+  else
+    NORM_DISPATCH(norm_fwd_kernel, 1, x, w, b, (bf16*)y, stats, M, D, eps);
+  return check_launch("norm_fwd");
+}
+
+extern "C" int vtp_norm_bwd(const void* dy, const float* x, const float* w, const float* stats, const float* dres,
+                            float* dx, void* dx_bf16, float* dw, float* db, int M, int D, int kind, void* stream) {
+  VTP_REQUIRE(dy && x && w && stats && dx, "vtp_norm_bwd: null pointer");
+  VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  VTP_REQUIRE(kind == 0 || kind == 1, "vtp_norm_bwd: kind must be 0 or 1");
+  int blocks = cdiv(M, 4);
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), block(256);
+  if (kind == 0)
+    NORM_DISPATCH(norm_bwd_kernel, 0, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, M, D);
+  else
+    NORM_DISPATCH(norm_bwd_kernel, 1, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, M, D);
+  return check_launch("norm_bwd");
+}

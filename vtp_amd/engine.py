@@ -1,0 +1,497 @@
+"""Hand-scheduled forward/backward of the VTP towers on the gfx950 kernels (no autograd inside).
+
+Data layout in HBM (one GPU, per tower):
+  * residual stream   f32  [B*N, D]   (token-major; encoder N = 1 + hw with the cls row first, decoder N = hw)
+  * GEMM operands     bf16 [rows, K]  K-contiguous; weights are bf16 copies (W and W^T) of the fp32 masters
+  * qkv               bf16 [B*N, 3D]  packed exactly like attention.py:115 (q | k | v, head-major inside each);
+                                      RoPE is applied in place, attention reads it with strides (no head transposes)
+  * saved for backward per block: x_in f32, xn1/xn2 bf16, (mean,rstd) f32, qkv bf16, o bf16, lse f32, x_mid f32,
+    x12 bf16 [M,2H] (SwiGLU pre-activations, 8|8 interleaved), hidden bf16 [M,H]  (~28 MB/image-batch-row for VTP-B;
+    288 GB of HBM3E makes recomputation pointless at these sizes)
+  * master params / grads: two flat f32 buffers (one fused AdamW launch, contiguous gradient buckets for RCCL).
+
+Reference call stack this replaces: SelfAttentionBlock._forward_list (block.py:290-296) ->
+SelfAttention.forward (attention.py:91-126) / SwiGLUFFN.forward (ffn.py:77-81), and their autograd backward.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import EPI_BF16, EPI_F32, EPI_F32_ATOMIC, EPI_GELU, EPI_SWIGLU, pad8
+
+
+# =====================================================================================================================
+# parameters: flat fp32 masters + flat fp32 grads + bf16 compute copies refreshed by ONE batched kernel
+# =====================================================================================================================
+class Lin:
+    """Compute-side record of one linear map y = x W^T + b  (W fp32 master [N,K])."""
+    __slots__ = ("N", "K", "w", "wT", "bias", "gw", "gb")
+
+
+class SwiGLULin:
+    """w1/w2 of SwiGLUFFN fused into one interleaved [2H, D] matrix (16-row groups = 8 rows w1 | 8 rows w2)."""
+    __slots__ = ("H", "K", "w12", "w12T", "b12", "gw1", "gb1")
+
+
+def _flat_order(names: List[str]) -> List[str]:
+    """Registration order, except that (w1.weight, w2.weight) and (w1.bias, w2.bias) are made adjacent (the SwiGLU
+    wgrad / bias-grad kernels de-interleave into `w1 | w2` with a single base pointer)."""
+    out, seen = [], set()
+    for n in names:
+        if n in seen:
+            continue
+        if n.endswith("mlp.w1.weight") or n.endswith("mlp.w1.bias"):
+            sib = n.replace("mlp.w1.", "mlp.w2.")
+            out += [n, sib]
+            seen.update((n, sib))
+        else:
+            out.append(n)
+            seen.add(n)
+    return out
+
+
+class ParamStore:
+    def __init__(self, module: torch.nn.Module, device: torch.device):
+        self.device = device
+        params = dict(module.named_parameters())
+        order = _flat_order(list(params.keys()))
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for n in order:
+            k = params[n].numel()
+            self.offsets[n] = (off, k)
+            off += (k + 3) // 4 * 4
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.params = params
+        with torch.no_grad():
+            for n in order:
+                o, k = self.offsets[n]
+                prm = params[n]
+                view = self.flat_p[o:o + k].view(prm.shape)
+                view.copy_(prm.detach().to(device=device, dtype=torch.float32))
+                prm.data = view
+                prm.grad = self.flat_g[o:o + k].view(prm.shape)
+        self._descs: List[List[int]] = []
+        self._bf16_elems = 0
+        self._bf16_allocs: List[Tuple[object, str, int, tuple]] = []
+        self._f32_extra: List[Tuple[object, str, int]] = []
+        self._desc_dev = None
+        self._tiles = 0
+        self._keep = []
+
+    # ---- views
+    def p(self, name: str) -> torch.Tensor:
+        o, k = self.offsets[name]
+        return self.flat_p[o:o + k]
+
+    def g(self, name: str) -> torch.Tensor:
+        o, k = self.offsets[name]
+        return self.flat_g[o:o + k]
+
+    def has(self, name: str) -> bool:
+        return name in self.offsets
+
+    # ---- registration of compute copies (finalize() allocates them in one flat bf16 buffer)
+    def _want_bf16(self, obj, attr, n_elems, shape):
+        self._bf16_allocs.append((obj, attr, self._bf16_elems, shape))
+        self._bf16_elems += (n_elems + 7) // 8 * 8
+
+    def lin(self, wname: str, bname: Optional[str], N: int, K: int, need_T: bool = True) -> Lin:
+        L = Lin()
+        L.N, L.K = N, K
+        assert self.offsets[wname][1] == N * K, (wname, N, K)
+        L.bias = self.p(bname) if bname and self.has(bname) else None
+        L.gw = self.g(wname)
+        L.gb = self.g(bname) if bname and self.has(bname) else None
+        L.wT = None
+        self._want_bf16(L, "w", N * K, (N, K))
+        if need_T:
+            self._want_bf16(L, "wT", N * K, (K, N))
+        self._descs.append(["lin", L, wname, need_T])
+        return L
+
+    def swiglu(self, prefix: str, H: int, K: int) -> SwiGLULin:
+        S = SwiGLULin()
+        S.H, S.K = H, K
+        o1, k1 = self.offsets[prefix + "w1.weight"]
+        o2, _ = self.offsets[prefix + "w2.weight"]
+        assert o2 == o1 + k1 and k1 == H * K
+        ob1, kb1 = self.offsets[prefix + "w1.bias"]
+        ob2, _ = self.offsets[prefix + "w2.bias"]
+        assert ob2 == ob1 + kb1 and kb1 == H
+        S.gw1 = self.flat_g[o1:o1 + 2 * k1]
+        S.gb1 = self.flat_g[ob1:ob1 + 2 * H]
+        self._want_bf16(S, "w12", 2 * H * K, (2 * H, K))
+        self._want_bf16(S, "w12T", 2 * H * K, (K, 2 * H))
+        self._descs.append(["swiglu", S, prefix])
+        return S
+
+    def finalize(self):
+        self.flat_bf16 = torch.zeros(max(self._bf16_elems, 8), dtype=torch.bfloat16, device=self.device)
+        for obj, attr, off, shape in self._bf16_allocs:
+            n = shape[0] * shape[1]
+            setattr(obj, attr, self.flat_bf16[off:off + n].view(shape))
+        rows, tiles = [], 0
+
+        def add(src, src2, dst, dstT, R, C, mode):
+            nonlocal tiles
+            rows.append([src, src2, dst, dstT, R, C, mode, tiles])
+            tiles += (R + 255) // 256 if mode == 2 else ((R + 63) // 64) * ((C + 63) // 64)
+
+        for d in self._descs:
+            if d[0] == "lin":
+                _, L, wname, need_T = d
+                add(self.p(wname).data_ptr(), 0, L.w.data_ptr(), L.wT.data_ptr() if need_T else 0, L.N, L.K, 0)
+            else:
+                _, S, prefix = d
+                b12 = torch.zeros(2 * S.H, dtype=torch.float32, device=self.device)
+                S.b12 = b12
+                self._keep.append(b12)
+                add(self.p(prefix + "w1.weight").data_ptr(), self.p(prefix + "w2.weight").data_ptr(), S.w12.data_ptr(),
+                    S.w12T.data_ptr(), 2 * S.H, S.K, 1)
+                add(self.p(prefix + "w1.bias").data_ptr(), self.p(prefix + "w2.bias").data_ptr(), b12.data_ptr(), 0,
+                    2 * S.H, 1, 2)
+        self._desc_dev = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._ndesc = len(rows)
+        self._tiles = tiles
+        self.prep()
+
+    def prep(self):
+        """Refresh every bf16 compute copy from the fp32 masters (one kernel launch)."""
+        ops.prep_weights(self._desc_dev, self._ndesc, self._tiles)
+        self._prepped_version = self.flat_p._version
+
+    def ensure_fresh(self):
+        if self.flat_p._version != self._prepped_version:
+            self.prep()
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+
+# =====================================================================================================================
+# buffers
+# =====================================================================================================================
+class Workspace:
+    """Named device buffers, allocated once per (name, shape, dtype) and reused every step (static memory plan)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
+    tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
+    s = max(1, min(round(768 / tiles), k // 256, 64))
+    return int(s)
+
+
+def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
+               x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0):
+    """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
+    Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
+    column sums for db ride along), W^T is the cached transposed weight."""
+    N = L.N if N is None else N
+    K = L.K if K is None else K
+    gw = L.gw if gw is None else gw
+    gb = L.gb if gb is None else gb
+    wT = L.wT if wT is None else wT
+    Mp = pad8(M)
+    dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
+    xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
+    ops.transpose_bf16(dy_b, dy_b.stride(0), dyT, Mp, M, N, colsum=gb, swiglu_h=swiglu_h, in_remap=dy_remap)
+    ops.transpose_bf16(x_b, x_b.stride(0), xT, Mp, M, K, in_remap=x_remap)
+    ops.gemm_nt(dyT, xT, gw, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, epi=EPI_F32_ATOMIC, splits=_wgrad_splits(N, K, Mp),
+                c_remap=(-1, swiglu_h) if swiglu_h else (0, 0))
+    if need_dx:
+        ops.gemm_nt(dy_b, wT, d_in, M=M, N=K, K=N, lda=dy_b.stride(0), ldb=N, ldc=d_in.stride(0), epi=EPI_BF16,
+                    a_remap=dy_remap, c_remap=dx_remap)
+
+
+# =====================================================================================================================
+# a run of SelfAttentionBlocks (block.py:137-308) -- shared by the ViT trunk and the pixel decoder
+# =====================================================================================================================
+class BlockW:
+    pass
+
+
+class Stack:
+    def __init__(self, store: ParamStore, prefix: str, depth: int, D: int, heads: int, H: int, norm: str):
+        self.store, self.depth, self.D, self.heads, self.H = store, depth, D, heads, H
+        self.kind = ops.NORM_RMS if norm == "rmsnorm" else ops.NORM_LN
+        self.eps = 1e-5 if norm == "rmsnorm" else 1e-6  # RMSNorm default / partial(nn.LayerNorm, eps=1e-6)
+        self.blocks: List[BlockW] = []
+        for i in range(depth):
+            b = BlockW()
+            pre = f"{prefix}{i}."
+            b.n1w, b.gn1w = store.p(pre + "norm1.weight"), store.g(pre + "norm1.weight")
+            b.n2w, b.gn2w = store.p(pre + "norm2.weight"), store.g(pre + "norm2.weight")
+            if self.kind == ops.NORM_LN:
+                b.n1b, b.gn1b = store.p(pre + "norm1.bias"), store.g(pre + "norm1.bias")
+                b.n2b, b.gn2b = store.p(pre + "norm2.bias"), store.g(pre + "norm2.bias")
+            else:
+                b.n1b = b.gn1b = b.n2b = b.gn2b = None
+            b.qkv = store.lin(pre + "attn.qkv.weight", pre + "attn.qkv.bias", 3 * D, D)
+            b.proj = store.lin(pre + "attn.proj.weight", pre + "attn.proj.bias", D, D)
+            b.w12 = store.swiglu(pre + "mlp.", H, D)
+            b.w3 = store.lin(pre + "mlp.w3.weight", pre + "mlp.w3.bias", D, H)
+            b.ls1 = store.p(pre + "ls1.gamma") if store.has(pre + "ls1.gamma") else None
+            b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
+            self.blocks.append(b)
+
+    # x: f32 [M, D] input residual.  Returns the output residual (f32 [M, D]).
+    def forward(self, ws: Workspace, x, B: int, N: int, rope, prefix_tokens: int, train: bool):
+        D, H, heads = self.D, self.H, self.heads
+        M = B * N
+        scale = 1.0 / math.sqrt(64.0)
+        for i, b in enumerate(self.blocks):
+            t = f"{i}." if train else ""
+            xn1 = ws.get(t + "xn1", (M, D), BF)
+            st1 = ws.get(t + "st1", (M, 2), F32)
+            qkv = ws.get(t + "qkv", (M, 3 * D), BF)
+            o = ws.get(t + "o", (M, D), BF)
+            lse = ws.get(t + "lse", (B, heads, N), F32)
+            xmid = ws.get(t + "xmid", (M, D), F32)
+            xn2 = ws.get(t + "xn2", (M, D), BF)
+            st2 = ws.get(t + "st2", (M, 2), F32)
+            x12 = ws.get(t + "x12", (M, 2 * H), BF) if train else None
+            hid = ws.get(t + "hid", (M, H), BF)
+            xout = ws.get((f"{i}.xout" if train else f"xout{i & 1}"), (M, D), F32)
+            b.x_in = x if train else None  # block input (previous block's xout buffer) is kept for norm1 backward
+
+            ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
+            ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
+            if rope is not None:
+                ops.rope_qk(qkv, rope[0], rope[1], B, N, heads, prefix_tokens)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, N, heads, N * 3 * D, 3 * D, N * D, D, scale)
+            ops.gemm_nt(o, b.proj.w, xmid, M=M, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, resid=x, epi=EPI_F32)
+            ops.norm_fwd(xmid, b.n2w, b.n2b, xn2, st2, M, D, self.eps, self.kind)
+            ops.gemm_nt(xn2, b.w12.w12, hid, M=M, N=2 * H, K=D, c2=x12, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            ops.gemm_nt(hid, b.w3.w, xout, M=M, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, resid=xmid, epi=EPI_F32)
+            if train:
+                b.saved = (xn1, st1, qkv, o, lse, xmid, xn2, st2, x12, hid)
+            x = xout
+        return x
+
+    # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
+    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, block_hook=None):
+        D, H, heads = self.D, self.H, self.heads
+        M = B * N
+        scale = 1.0 / math.sqrt(64.0)
+        dh = ws.get("b.dh", (M, H), BF)
+        dx12 = ws.get("b.dx12", (M, 2 * H), BF)
+        dxn = ws.get("b.dxn", (M, D), BF)
+        d_o = ws.get("b.do", (M, D), BF)
+        dqkv = ws.get("b.dqkv", (M, 3 * D), BF)
+        delta = ws.get("b.delta", (B, heads, N), F32)
+        dmid = ws.get("b.dmid", (M, D), F32)
+        dmid_b = ws.get("b.dmid_b", (M, D), BF)
+        for i in range(self.depth - 1, -1, -1):
+            b = self.blocks[i]
+            assert b.ls1 is None and b.ls2 is None, "LayerScale backward is not implemented"
+            xn1, st1, qkv, o, lse, xmid, xn2, st2, x12, hid = b.saved
+            dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
+            dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
+            # ---- FFN: x_out = x_mid + w3(silu(w1 xn2) * (w2 xn2))
+            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh)
+            ops.swiglu_bwd(dh, x12, dx12, M, H)
+            linear_bwd(ws, "w12", None, dx12, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
+                       swiglu_h=H)
+            ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind)
+            # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
+            linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o)
+            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, d_o, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], B, N, heads,
+                         N * 3 * D, 3 * D, N * D, D, scale)
+            if rope is not None:
+                ops.rope_qk(dqkv, rope[0], rope[1], B, N, heads, prefix_tokens, inverse=True)
+            linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
+            ops.norm_bwd(dxn, b.x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
+            dy, dy_b = dxo, dxo_b
+            if block_hook is not None:
+                block_hook(i)  # all parameter gradients of block i are enqueued
+        return dy, dy_b
+
+
+# =====================================================================================================================
+# RoPE tables (host, cached): exact op order of RopePositionEmbedding.forward (embeddings.py:131-180) in the dtype of
+# the `periods` buffer (bf16) -- recomputing sin/cos in fp32 on the device would NOT match the reference
+# =====================================================================================================================
+_ROPE_CACHE: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def rope_tables(periods: torch.Tensor, H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    per = periods.detach().to("cpu")
+    key = (H, W, str(device), per.dtype, tuple(per.float().tolist()))
+    hit = _ROPE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    dd = {"dtype": per.dtype}
+    ch = torch.arange(0.5, H, **dd) / H
+    cw = torch.arange(0.5, W, **dd) / W
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
+    coords = 2.0 * coords - 1.0
+    ang = 2 * math.pi * coords[:, :, None] / per[None, None, :]
+    ang = ang.flatten(1, 2).tile(2)
+    sin = torch.sin(ang).to(torch.bfloat16).contiguous().to(device)
+    cos = torch.cos(ang).to(torch.bfloat16).contiguous().to(device)
+    _ROPE_CACHE[key] = (sin, cos)
+    return sin, cos
+
+
+# =====================================================================================================================
+# ViT trunk with bottleneck (vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79)
+# =====================================================================================================================
+class TrunkEngine:
+    def __init__(self, store: ParamStore, cfg, periods: torch.Tensor):
+        from .config import swiglu_hidden
+        self.store = store
+        self.D, self.heads, self.depth = cfg.vision_embed_dim, cfg.vision_num_heads, cfg.vision_depth
+        self.H = swiglu_hidden(self.D, cfg.vision_mlp_ratio)
+        self.kind = ops.NORM_RMS if cfg.vision_norm_layer == "rmsnorm" else ops.NORM_LN
+        self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
+        self.periods = periods
+        self.pe = store.lin("trunk.patch_embed.proj.weight", "trunk.patch_embed.proj.bias", self.D, 768, need_T=False)
+        self.stack = Stack(store, "trunk.blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
+        self.bott_dim = cfg.vision_feature_bottleneck
+        self.bott = store.lin("trunk.feature_bottleneck.weight", None, self.bott_dim, self.D) \
+            if store.has("trunk.feature_bottleneck.weight") else None
+        self.ws: Dict[tuple, Workspace] = {}
+
+    def workspace(self, B, Hh, Ww) -> Workspace:
+        key = (B, Hh, Ww)
+        if key not in self.ws:
+            self.ws[key] = Workspace(self.store.device)
+        return self.ws[key]
+
+    def forward(self, img: torch.Tensor, train: bool, masks: Optional[torch.Tensor] = None):
+        """img f32 [B,3,H,W] -> final-norm tokens xnf bf16 [B*N, D] (N = 1 + hw)."""
+        st = self.store
+        B, _, Hh, Ww = img.shape
+        h, w = Hh // 16, Ww // 16
+        hw, N, D = h * w, h * w + 1, self.D
+        M = B * N
+        ws = self.workspace(B, Hh, Ww)
+        patches = ws.get("patches", (B * hw, 768), BF)
+        x0 = ws.get("x0", (M, D), F32)
+        ops.im2col16(img, patches, B, Hh, Ww)
+        ops.gemm_nt(patches, self.pe.w, x0, M=B * hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(hw, 1))
+        ops.assemble_tokens(x0, st.p("trunk.cls_token"), st.p("trunk.mask_token"), masks, B, N, D)
+        rope = rope_tables(self.periods, h, w, st.device)
+        xl = self.stack.forward(ws, x0, B, N, rope, 1, train)
+        xnf = ws.get("xnf", (M, D), BF)
+        stf = ws.get("stf", (M, 2), F32)
+        ops.norm_fwd(xl, st.p("trunk.norm.weight"), st.p("trunk.norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf,
+                     M, D, self.eps, self.kind)
+        self._ctx = (ws, B, h, w, xl, xnf, stf, rope, patches, masks)
+        return xnf
+
+    def latents(self, out_f32: bool = False) -> torch.Tensor:
+        """bottleneck on the patch rows of the last forward -> [B*hw, 64] (bf16, or f32 for the API boundary)."""
+        ws, B, h, w, _, xnf, _, _, _, _ = self._ctx
+        hw = h * w
+        lat = ws.get("lat32" if out_f32 else "lat", (B * hw, self.bott_dim), F32 if out_f32 else BF)
+        ops.gemm_nt(xnf, self.bott.w, lat, M=B * hw, N=self.bott_dim, K=self.D, epi=EPI_F32 if out_f32 else EPI_BF16,
+                    a_remap=(hw, 1))
+        return lat
+
+    def backward(self, d_lat: Optional[torch.Tensor], after_tail=None, block_hook=None):
+        """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g."""
+        st = self.store
+        ws, B, h, w, xl, xnf, stf, rope, patches, masks = self._ctx
+        assert masks is None, "mask-token backward is not implemented yet"
+        hw, N, D = h * w, h * w + 1, self.D
+        M = B * N
+        d_xnf = ws.get("b.d_xnf", (M, D), BF, zero=True)  # cls rows stay zero unless a cls-path gradient is added
+        if d_lat is not None:
+            linear_bwd(ws, "bott", self.bott, d_lat, xnf, B * hw, d_xnf, x_remap=(hw, 1), dx_remap=(hw, 1))
+        dx = ws.get("b.dxt", (M, D), F32)
+        dx_b = ws.get("b.dxt_b", (M, D), BF)
+        ops.norm_bwd(d_xnf, xl, st.p("trunk.norm.weight"), stf, None, dx, dx_b, st.g("trunk.norm.weight"),
+                     st.g("trunk.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
+        if after_tail is not None:
+            after_tail()
+        dx0, dx0_b = self.stack.backward(ws, dx, dx_b, B, N, rope, 1, block_hook)
+        # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
+        linear_bwd(ws, "pe", self.pe, dx0_b, patches, B * hw, None, need_dx=False, dy_remap=(hw, 1))
+        ops.strided_rowsum(dx0, N * D, st.g("trunk.cls_token"), B, D)
+
+
+# =====================================================================================================================
+# pixel decoder (pixel_decoder.py:134-162): 1x1 conv -> blocks -> LN -> 1x1 conv -> PixelShuffle(16)
+# =====================================================================================================================
+class DecoderEngine:
+    def __init__(self, store: ParamStore, cfg, periods: torch.Tensor):
+        from .config import swiglu_hidden
+        self.store = store
+        self.D, self.heads, self.depth = cfg.decoder_embed_dim, cfg.decoder_num_heads, cfg.decoder_depth
+        self.H = swiglu_hidden(self.D, 4.0)
+        self.kind = ops.NORM_RMS if cfg.decoder_norm_layer == "rmsnorm" else ops.NORM_LN
+        self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
+        self.periods = periods
+        self.cin = cfg.vision_feature_bottleneck
+        self.pin = store.lin("pixel_decoder.proj_in.weight", "pixel_decoder.proj_in.bias", self.D, self.cin)
+        self.stack = Stack(store, "pixel_decoder.blocks.", self.depth, self.D, self.heads, self.H, cfg.decoder_norm_layer)
+        self.pout = store.lin("pixel_decoder.proj_out.weight", "pixel_decoder.proj_out.bias", 768, self.D)
+        self.ws: Dict[tuple, Workspace] = {}
+
+    def workspace(self, B, h, w) -> Workspace:
+        key = (B, h, w)
+        if key not in self.ws:
+            self.ws[key] = Workspace(self.store.device)
+        return self.ws[key]
+
+    def forward(self, lat: torch.Tensor, B: int, h: int, w: int, train: bool) -> torch.Tensor:
+        """lat bf16 [B*hw, 64] token-major -> t bf16 [B*hw, 768] (pre-PixelShuffle, token-major)."""
+        st = self.store
+        M, D = B * h * w, self.D
+        ws = self.workspace(B, h, w)
+        x0 = ws.get("x0", (M, D), F32)
+        ops.gemm_nt(lat, self.pin.w, x0, M=M, N=D, K=self.cin, bias=self.pin.bias, epi=EPI_F32)
+        rope = rope_tables(self.periods, h, w, st.device)
+        xl = self.stack.forward(ws, x0, B, h * w, rope, 0, train)
+        xnf = ws.get("xnf", (M, D), BF)
+        stf = ws.get("stf", (M, 2), F32)
+        ops.norm_fwd(xl, st.p("pixel_decoder.norm.weight"),
+                     st.p("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf, M, D, self.eps, self.kind)
+        t = ws.get("t", (M, 768), BF)
+        ops.gemm_nt(xnf, self.pout.w, t, M=M, N=768, K=D, bias=self.pout.bias, epi=EPI_BF16)
+        self._ctx = (ws, B, h, w, lat, xl, xnf, stf, rope)
+        return t
+
+    def backward(self, dt: torch.Tensor, after_tail=None, block_hook=None) -> torch.Tensor:
+        """dt bf16 [B*hw, 768] -> d_lat bf16 [B*hw, 64]; parameter grads accumulate into store.flat_g."""
+        st = self.store
+        ws, B, h, w, lat, xl, xnf, stf, rope = self._ctx
+        M, D = B * h * w, self.D
+        d_xnf = ws.get("b.d_xnf", (M, D), BF)
+        linear_bwd(ws, "pout", self.pout, dt, xnf, M, d_xnf)
+        dx = ws.get("b.dxt", (M, D), F32)
+        dx_b = ws.get("b.dxt_b", (M, D), BF)
+        ops.norm_bwd(d_xnf, xl, st.p("pixel_decoder.norm.weight"), stf, None, dx, dx_b, st.g("pixel_decoder.norm.weight"),
+                     st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
+        if after_tail is not None:
+            after_tail()
+        dx0, dx0_b = self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, block_hook)
+        d_lat = ws.get("b.d_lat", (M, self.cin), BF)
+        linear_bwd(ws, "pin", self.pin, dx0_b, lat, M, d_lat)
+        return d_lat

@@ -1,0 +1,339 @@
+"""VTPModel -- MI355X-native drop-in for the reference ``VTPModel``
+(vtp/models/vtp_hf/modeling_vtp.py:51-472): same constructor (a VTPConfig), same public methods, same
+``state_dict`` keys / shapes (so reference checkpoints load unchanged), but every tower runs on the
+hand-written gfx950 kernels of libvtp_hip.so through vtp_amd.engine (there is no PyTorch-eager fallback).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .config import VTPConfig, swiglu_hidden
+from .engine import BF, F32, DecoderEngine, ParamStore, TrunkEngine
+
+
+def _holder() -> nn.Module:
+    return nn.Module()
+
+
+def _param(*shape) -> nn.Parameter:
+    return nn.Parameter(torch.empty(*shape))
+
+
+def _linear(out_f: int, in_f: int, bias: bool = True) -> nn.Module:
+    m = _holder()
+    m.weight = _param(out_f, in_f)
+    if bias:
+        m.bias = _param(out_f)
+    return m
+
+
+def _norm(dim: int, bias: bool) -> nn.Module:
+    m = _holder()
+    m.weight = _param(dim)
+    if bias:
+        m.bias = _param(dim)
+    return m
+
+
+def _vit_block(D: int, H: int, norm: str) -> nn.Module:
+    """Parameter tree of SelfAttentionBlock (block.py:159-187)."""
+    b = _holder()
+    b.norm1 = _norm(D, norm != "rmsnorm")
+    b.attn = _holder()
+    b.attn.qkv = _linear(3 * D, D)
+    b.attn.proj = _linear(D, D)
+    b.norm2 = _norm(D, norm != "rmsnorm")
+    b.mlp = _holder()
+    b.mlp.w1 = _linear(H, D)
+    b.mlp.w2 = _linear(H, D)
+    b.mlp.w3 = _linear(D, H)
+    return b
+
+
+def _rope_periods(head_dim: int = 64, base: float = 100.0) -> torch.Tensor:
+    """RopePositionEmbedding._init_weights (embeddings.py:182-195), bf16 like the reference default."""
+    dt = torch.bfloat16
+    return base ** (2 * torch.arange(head_dim // 4, dtype=dt) / (head_dim // 2))
+
+
+class VTPModel(nn.Module):
+    config_class = VTPConfig
+
+    def __init__(self, config: VTPConfig):
+        super().__init__()
+        self.config = config
+        c = config
+        D, Dd, Dt = c.vision_embed_dim, c.decoder_embed_dim, c.text_embed_dim
+        # ---- trunk (DinoVisionTransformerWithBottleneck)
+        t = _holder()
+        t.cls_token = _param(1, 1, D)
+        t.mask_token = _param(1, D)
+        t.patch_embed = _holder()
+        t.patch_embed.proj = _holder()
+        t.patch_embed.proj.weight = _param(D, 3, 16, 16)
+        t.patch_embed.proj.bias = _param(D)
+        t.rope_embed = _holder()
+        t.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
+        Hv = swiglu_hidden(D, c.vision_mlp_ratio)
+        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer) for _ in range(c.vision_depth)])
+        t.norm = _norm(D, c.vision_norm_layer != "rmsnorm")
+        if c.vision_feature_bottleneck is not None and c.vision_feature_bottleneck != D:
+            t.feature_bottleneck = _holder()
+            t.feature_bottleneck.weight = _param(c.vision_feature_bottleneck, D)
+        self.trunk = t
+        eff = c.vision_feature_bottleneck if hasattr(t, "feature_bottleneck") else D
+        if c.train_clip:
+            self.visual_proj = _holder()
+            self.visual_proj.weight = _param(Dt, D if c.vision_bottleneck_ae_only else eff)
+        else:
+            self.visual_proj = None
+        # ---- pixel decoder (DinoV3PixelDecoder)
+        if c.train_reconstruction:
+            d = _holder()
+            d.proj_in = _holder()
+            d.proj_in.weight = _param(Dd, eff, 1, 1)
+            d.proj_in.bias = _param(Dd)
+            d.rope_embed = _holder()
+            d.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
+            Hd = swiglu_hidden(Dd, 4.0)
+            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer) for _ in range(c.decoder_depth)])
+            d.norm = _norm(Dd, c.decoder_norm_layer != "rmsnorm")
+            d.proj_out = _holder()
+            d.proj_out.weight = _param(768, Dd, 1, 1)
+            d.proj_out.bias = _param(768)
+            self.pixel_decoder = d
+        else:
+            self.pixel_decoder = None
+        # ---- CLIP text tower (TextTransformer pieces as re-hung by VTPModel._init_text_components)
+        if c.train_clip:
+            tt = _holder()
+            blocks = []
+            for _ in range(c.text_depth):
+                r = _holder()
+                r.ln_1 = _norm(Dt, True)
+                r.attn = _holder()
+                r.attn.in_proj_weight = _param(3 * Dt, Dt)
+                r.attn.in_proj_bias = _param(3 * Dt)
+                r.attn.out_proj = _linear(Dt, Dt)
+                r.ln_2 = _norm(Dt, True)
+                r.mlp = _holder()
+                r.mlp.c_fc = _linear(int(Dt * c.text_mlp_ratio), Dt)
+                r.mlp.c_proj = _linear(Dt, int(Dt * c.text_mlp_ratio))
+                blocks.append(r)
+            tt.resblocks = nn.ModuleList(blocks)
+            self.text_transformer = tt
+            self.token_embedding = _holder()
+            self.token_embedding.weight = _param(c.text_vocab_size, Dt)
+            self.positional_embedding = _param(c.text_context_length, Dt)
+            self.ln_final = _norm(Dt, True)
+            self.text_projection = _param(Dt, Dt)
+            self.context_length, self.vocab_size = c.text_context_length, c.text_vocab_size
+            lshape = [1] if c.nonscalar_logit_scale else []
+            self.logit_scale = nn.Parameter(torch.ones(lshape) * (c.init_logit_scale or np.log(1 / 0.07)))
+        self.logit_bias = None
+        self.reset_parameters()
+        self._store: Optional[ParamStore] = None
+
+    # ------------------------------------------------------------------------------------------------ init
+    @torch.no_grad()
+    def reset_parameters(self):
+        """Same distributions as the reference init (init_weights_vit vision_transformer.py:43-55, PatchEmbed
+        embeddings.py:79-83, decoder pixel_decoder.py:122-131, text text_transformer.py:304-327)."""
+        c = self.config
+
+        def vit(prefix_mod):
+            for name, p in prefix_mod.named_parameters():
+                if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                elif name.endswith(".weight") and p.ndim == 2:
+                    nn.init.trunc_normal_(p, std=0.02)
+
+        vit(self.trunk)
+        nn.init.normal_(self.trunk.cls_token, std=0.02)
+        self.trunk.mask_token.zero_()
+        k = 1.0 / (3 * 16 * 16)
+        self.trunk.patch_embed.proj.weight.uniform_(-math.sqrt(k), math.sqrt(k))
+        self.trunk.patch_embed.proj.bias.uniform_(-math.sqrt(k), math.sqrt(k))
+        if self.visual_proj is not None:
+            nn.init.trunc_normal_(self.visual_proj.weight, std=0.02)
+        if self.pixel_decoder is not None:
+            vit(self.pixel_decoder)
+            for m in (self.pixel_decoder.proj_in, self.pixel_decoder.proj_out):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                m.bias.zero_()
+        if c.train_clip:
+            W, L = c.text_embed_dim, c.text_depth
+            nn.init.normal_(self.token_embedding.weight, std=0.02)
+            nn.init.normal_(self.positional_embedding, std=0.01)
+            proj_std, attn_std, fc_std = (W ** -0.5) * ((2 * L) ** -0.5), W ** -0.5, (2 * W) ** -0.5
+            for r in self.text_transformer.resblocks:
+                nn.init.normal_(r.attn.in_proj_weight, std=attn_std)
+                r.attn.in_proj_bias.zero_()
+                nn.init.normal_(r.attn.out_proj.weight, std=proj_std)
+                r.attn.out_proj.bias.zero_()
+                nn.init.normal_(r.mlp.c_fc.weight, std=fc_std)
+                r.mlp.c_fc.bias.zero_()
+                nn.init.normal_(r.mlp.c_proj.weight, std=proj_std)
+                r.mlp.c_proj.bias.zero_()
+                for ln in (r.ln_1, r.ln_2):
+                    ln.weight.fill_(1.0)
+                    ln.bias.zero_()
+            self.ln_final.weight.fill_(1.0)
+            self.ln_final.bias.zero_()
+            nn.init.normal_(self.text_projection, std=W ** -0.5)
+
+    # ------------------------------------------------------------------------------------------------ engine plumbing
+    def _engine(self) -> ParamStore:
+        if self._store is None:
+            dev = self.trunk.cls_token.device
+            if dev.type != "cuda":
+                raise RuntimeError("vtp_amd.VTPModel runs only on an MI355X (HIP) device: call model.cuda() first. "
+                                   "There is no CPU / eager fallback.")
+            st = ParamStore(self, dev)
+            self._trunk = TrunkEngine(st, self.config, self.trunk.rope_embed.periods)
+            self._decoder = DecoderEngine(st, self.config, self.pixel_decoder.rope_embed.periods) \
+                if self.pixel_decoder is not None else None
+            if self.visual_proj is not None:
+                self._vproj = st.lin("visual_proj.weight", None, self.visual_proj.weight.shape[0],
+                                     self.visual_proj.weight.shape[1])
+            st.finalize()
+            self._store = st
+            self._pver = self._param_version()
+        return self._store
+
+    def _param_version(self) -> int:
+        return sum(p._version for p in self.parameters())
+
+    def refresh_weights(self):
+        """Re-derive the bf16 compute copies after the fp32 parameters were modified outside the fused optimizer."""
+        self._engine().prep()
+        self._pver = self._param_version()
+
+    def _fresh(self) -> ParamStore:
+        st = self._engine()
+        if self._param_version() != self._pver:
+            self.refresh_weights()
+        return st
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._store is not None:
+            self.refresh_weights()
+        return out
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def save_pretrained(self, path: str):
+        from safetensors.torch import save_file
+        self.config.save_pretrained(path)
+        save_file({k: v.detach().contiguous().cpu() for k, v in self.state_dict().items()},
+                  os.path.join(path, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, path: str, device: Optional[str] = None) -> "VTPModel":
+        from safetensors.torch import load_file
+        model = cls(VTPConfig.from_pretrained(path))
+        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")), strict=True)
+        return model.to(device) if device else model
+
+    # ------------------------------------------------------------------------------------------------ API (inference)
+    @staticmethod
+    def _img(image: torch.Tensor) -> torch.Tensor:
+        if image.ndim != 4 or image.shape[1] != 3 or image.shape[2] % 16 or image.shape[3] % 16:
+            raise ValueError(f"image must be [B,3,H,W] with H,W multiples of 16, got {tuple(image.shape)}")
+        return image.detach().to(dtype=torch.float32).contiguous()
+
+    @torch.no_grad()
+    def get_reconstruction_latents(self, image: torch.Tensor) -> torch.Tensor:
+        """modeling_vtp.py:337-360 -> [B, 64, H/16, W/16] (f32)."""
+        self._fresh()
+        img = self._img(image)
+        B, _, H, W = img.shape
+        self._trunk.forward(img, train=False)
+        lat = self._trunk.latents(out_f32=True)  # [B*hw, 64]
+        return lat.view(B, (H // 16) * (W // 16), -1).transpose(1, 2).reshape(B, -1, H // 16, W // 16).clone()
+
+    @torch.no_grad()
+    def get_latents_decoded_images(self, latents: torch.Tensor) -> torch.Tensor:
+        """modeling_vtp.py:362-377 -> [B, 3, H, W] (f32)."""
+        if self.pixel_decoder is None:
+            raise RuntimeError("Reconstruction not enabled. Set train_reconstruction=True in config.")
+        self._fresh()
+        B, C, h, w = latents.shape
+        lat = latents.detach().reshape(B, C, h * w).transpose(1, 2).to(torch.bfloat16).contiguous().view(B * h * w, C)
+        t = self._decoder.forward(lat, B, h, w, train=False)
+        img = torch.empty(B, 3, h * 16, w * 16, dtype=torch.float32, device=lat.device)
+        ops.pixel_shuffle16(t, img, B, h, w)
+        return img
+
+    @torch.no_grad()
+    def get_last_layer_feature(self, image: torch.Tensor, use_bottleneck: bool = False) -> Dict[str, torch.Tensor]:
+        """modeling_vtp.py:184-215."""
+        self._fresh()
+        img = self._img(image)
+        B, _, H, W = img.shape
+        hw = (H // 16) * (W // 16)
+        xnf = self._trunk.forward(img, train=False).view(B, hw + 1, -1).float()
+        cls_t, patch_t = xnf[:, 0], xnf[:, 1:]
+        if use_bottleneck and self._trunk.bott is not None:
+            wb = self.trunk.feature_bottleneck.weight
+            patch_t = self._trunk.latents(out_f32=True).view(B, hw, -1).clone()
+            cls_b = torch.empty(B, wb.shape[0], dtype=torch.float32, device=img.device)
+            ops.gemm_nt(self._trunk._ctx[5], self._trunk.bott.w, cls_b, M=B, N=wb.shape[0], K=wb.shape[1],
+                        lda=(hw + 1) * wb.shape[1], epi=ops.EPI_F32)
+            cls_t = cls_b
+        return {"cls_token": cls_t.contiguous(), "patch_tokens": patch_t.contiguous()}
+
+    @torch.no_grad()
+    def get_clip_image_feature(self, image: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """modeling_vtp.py:244-276."""
+        if self.visual_proj is None:
+            raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
+        self._fresh()
+        c = self.config
+        if c.vision_clip_feat != "cls" or not c.vision_bottleneck_ae_only:
+            raise NotImplementedError("only vision_clip_feat='cls' with vision_bottleneck_ae_only=True is implemented")
+        img = self._img(image)
+        B, _, H, W = img.shape
+        N = (H // 16) * (W // 16) + 1
+        xnf = self._trunk.forward(img, train=False)  # [B*N, D] bf16; cls rows are b*N
+        D = c.vision_embed_dim
+        f = torch.empty(B, self._vproj.N, dtype=torch.float32, device=img.device)
+        ops.gemm_nt(xnf, self._vproj.w, f, M=B, N=self._vproj.N, K=D, lda=N * D, epi=ops.EPI_F32)
+        return torch.nn.functional.normalize(f, dim=-1) if normalize else f
+
+    def get_clip_text_feature(self, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        if not self.config.train_clip:
+            raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
+        raise NotImplementedError("text tower kernels land with the contrastive path (DESIGN.md 'next')")
+
+    def forward(self, image=None, text=None, forward_type: str = "clip"):
+        """modeling_vtp.py:399-472 (inference semantics)."""
+        if forward_type == "rec":
+            if image is None:
+                raise ValueError("image is required for reconstruction")
+            lat = self.get_reconstruction_latents(image)
+            return {"latents": lat, "reconstructed_image": self.get_latents_decoded_images(lat), "target_image": image}
+        if forward_type == "feature":
+            if image is None:
+                raise ValueError("image is required for feature extraction")
+            f = self.get_last_layer_feature(image, use_bottleneck=True)
+            return f
+        if forward_type == "clip":
+            out = {}
+            if image is not None:
+                out["image_features"] = self.get_clip_image_feature(image, normalize=True)
+            if text is not None:
+                out["text_features"] = self.get_clip_text_feature(text, normalize=True)
+            out["logit_scale"] = self.logit_scale.exp()
+            return out
+        raise ValueError(f"Invalid forward_type: {forward_type}")

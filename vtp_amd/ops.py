@@ -1,0 +1,120 @@
+"""Thin torch-tensor front end over the C ABI (include/vtp_hip.h).  Tensors only provide device memory and the
+current HIP stream; every op below is a hand-written gfx950 kernel in libvtp_hip.so."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_F32, EPI_SWIGLU, EPI_GELU, EPI_F32_ATOMIC = 0, 1, 2, 3, 4
+NORM_RMS, NORM_LN = 0, 1
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _lib_():
+    return _lib.load()
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def gemm_nt(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, c2=None, ldc2=0, bias=None, gamma=None,
+            resid=None, epi=EPI_BF16, a_remap=(0, 0), c_remap=(0, 0), splits=1, alpha=1.0):
+    """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b bf16 (K-contiguous rows)."""
+    M = a.shape[0] if M is None else M
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    ldc = c.stride(0) if ldc is None else ldc
+    if c2 is not None and not ldc2:
+        ldc2 = c2.stride(0)
+    rc = _lib_().vtp_gemm_nt(_p(a), lda, _p(b), ldb, _p(c), ldc, _p(c2), ldc2, _p(bias), _p(gamma), _p(resid), M, N, K,
+                             epi, a_remap[0], a_remap[1], c_remap[0], c_remap[1], splits, alpha, _s())
+    _lib.check(rc, "vtp_gemm_nt")
+
+
+def norm_fwd(x, w, b, y, stats, M, D, eps, kind):
+    _lib.check(_lib_().vtp_norm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, D, eps, kind, _s()), "vtp_norm_fwd")
+
+
+def norm_bwd(dy, x, w, stats, dres, dx, dxb, dw, db, M, D, kind):
+    _lib.check(_lib_().vtp_norm_bwd(_p(dy), _p(x), _p(w), _p(stats), _p(dres), _p(dx), _p(dxb), _p(dw), _p(db), M, D, kind,
+                                    _s()), "vtp_norm_bwd")
+
+
+def rope_qk(qkv, sin, cos, B, N, heads, prefix, inverse=False):
+    _lib.check(_lib_().vtp_rope_qk(_p(qkv), _p(sin), _p(cos), B, N, heads, prefix, int(inverse), _s()), "vtp_rope_qk")
+
+
+def attn_fwd(q, k, v, o, lse, B, N, heads, sb, sn, sbo, sno, scale, causal=False):
+    _lib.check(_lib_().vtp_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, N, heads, sb, sn, sbo, sno, scale, int(causal),
+                                    _s()), "vtp_attn_fwd")
+
+
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, N, heads, sb, sn, sbo, sno, scale, causal=False):
+    _lib.check(_lib_().vtp_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, N,
+                                    heads, sb, sn, sbo, sno, scale, int(causal), _s()), "vtp_attn_bwd")
+
+
+def im2col16(img, patches, B, H, W):
+    _lib.check(_lib_().vtp_im2col16(_p(img), _p(patches), B, H, W, _s()), "vtp_im2col16")
+
+
+def assemble_tokens(x, cls, mask_token, masks, B, N, D):
+    _lib.check(_lib_().vtp_assemble_tokens(_p(x), _p(cls), _p(mask_token), _p(masks), B, N, D, _s()), "vtp_assemble_tokens")
+
+
+def transpose_bf16(inp, ld_in, out, ld_out, R, C, colsum=None, swiglu_h=0, in_remap=(0, 0)):
+    _lib.check(_lib_().vtp_transpose_bf16(_p(inp), ld_in, _p(out), ld_out, _p(colsum), swiglu_h, in_remap[0], in_remap[1],
+                                          R, C, _s()), "vtp_transpose_bf16")
+
+
+def strided_rowsum(inp, stride, out, B, D):
+    _lib.check(_lib_().vtp_strided_rowsum(_p(inp), stride, _p(out), B, D, _s()), "vtp_strided_rowsum")
+
+
+def cast_f32_bf16(inp, out, n):
+    _lib.check(_lib_().vtp_cast_f32_bf16(_p(inp), _p(out), n, _s()), "vtp_cast_f32_bf16")
+
+
+def cast_transpose_f32_bf16(inp, out, R, C):
+    _lib.check(_lib_().vtp_cast_transpose_f32_bf16(_p(inp), _p(out), R, C, _s()), "vtp_cast_transpose_f32_bf16")
+
+
+def prep_weights(descs, n, total_tiles):
+    _lib.check(_lib_().vtp_prep_weights(_p(descs), n, total_tiles, _s()), "vtp_prep_weights")
+
+
+def swiglu_bwd(dh, x12, dx12, M, H):
+    _lib.check(_lib_().vtp_swiglu_bwd(_p(dh), _p(x12), _p(dx12), M, H, _s()), "vtp_swiglu_bwd")
+
+
+def gelu_bwd(dy, pre, dx, n):
+    _lib.check(_lib_().vtp_gelu_bwd(_p(dy), _p(pre), _p(dx), n, _s()), "vtp_gelu_bwd")
+
+
+def pixel_shuffle16(t, img, B, h, w):
+    _lib.check(_lib_().vtp_pixel_shuffle16(_p(t), _p(img), B, h, w, _s()), "vtp_pixel_shuffle16")
+
+
+def l1_loss_fwd_bwd(t, target, dt, loss_sum, B, h, w, gscale):
+    _lib.check(_lib_().vtp_l1_loss_fwd_bwd(_p(t), _p(target), _p(dt), _p(loss_sum), B, h, w, gscale, _s()),
+               "vtp_l1_loss_fwd_bwd")
+
+
+def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _lib.check(_lib_().vtp_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, wd, step, grad_scale,
+                                 _s()), "vtp_adamw")
+
+
+def ema(t, s, n, momentum):
+    _lib.check(_lib_().vtp_ema(_p(t), _p(s), n, momentum, _s()), "vtp_ema")
