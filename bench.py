@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +113,7 @@ def main():
     B = args.batch or B
     torch.manual_seed(0)
     model = VTPModel(VTPConfig(**cfg_kw)).to(dev)
-    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs)
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
 
     def sync():
@@ -152,6 +153,7 @@ def main():
 
         import vtp_amd.engine as eng
         ops.gemm_nt = timed_gemm
+        trainer.use_graphs = False  # the instrumented step launches eagerly (events cannot sit inside a replayed graph)
         try:
             trainer.step_rec(img)
             torch.cuda.synchronize()
@@ -184,7 +186,7 @@ def main():
         "config": {"workload": f"{args.workload}: full optimizer step (fwd + L1 recon loss + bwd + grad all-reduce + AdamW) "
                                f"of VTPModel trunk+pixel_decoder, {B} img/GPU @ {res}x{res}, random-init weights; "
                                "contrastive + SSL heads of config 3 not yet in the step",
-                   "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
+                   "launch": "eager" if args.no_graphs else "hipGraph segments", "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
                    "train_gflop_per_image": round(gflop_img, 1)},
         "loss": round(loss_val, 5),
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),

@@ -40,9 +40,15 @@ const char* vtp_last_error(void);
  *   VTP_EPI_F32         C f32  = resid + gamma * (acc + bias)            (bias/gamma/resid optional; block.py:293-294)
  *   VTP_EPI_SWIGLU      B rows interleaved [8 x w1 | 8 x w2] per 16; C bf16 [M, N/2] = silu(x1) * x2, C2 bf16 [M,N] = (x1|x2)
  *   VTP_EPI_GELU        C bf16 = gelu_erf(acc + bias), C2 bf16 = acc + bias (optional)
- *   VTP_EPI_F32_ATOMIC  C f32 += alpha * acc, split-K over `splits` slices (wgrad)
+ *   VTP_EPI_F32_ATOMIC  C f32 += alpha * acc, split-K over `splits` slices with fp32 atomics
+ *   VTP_EPI_F32_SLAB    split-K slice z writes alpha * acc to C + z * (4*ldc2) floats with plain stores (wgrad; sum the
+ *                       slabs with vtp_reduce_slabs).  The slice count actually used is vtp_gemm_splits(K, splits).
  */
-enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4 };
+enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4, VTP_EPI_F32_SLAB = 5 };
+int vtp_gemm_splits(int K, int splits);
+/* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
+ * workgroup remap.  Process-global; not part of the reference-facing surface. */
+int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
 int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);
@@ -118,6 +124,11 @@ int vtp_l1_loss_fwd_bwd(const void* t, const float* target, void* dt, float* los
 /* fused AdamW over one flat f32 parameter buffer (torch.optim.AdamW semantics); also refreshes the bf16 copy. */
 int vtp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* same, hyper-parameters read from DEVICE memory: hyper[8] = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t,
+ * sqrt(1-beta2^t), grad_scale} -- lets a captured hipGraph of the training step replay with per-step values. */
+int vtp_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hyper, void* stream);
+/* dst[i] (+)= sum_{s<S} slabs[s*stride + i], f32 (split-K partials -> gradient buffer). */
+int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n, int accumulate, void* stream);
 /* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
 int vtp_ema(float* t, const float* s, long n, float momentum, void* stream);
 

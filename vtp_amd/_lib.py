@@ -29,6 +29,10 @@ SIGNATURES = {
     "vtp_pixel_shuffle16": [_P, _P, _I, _I, _I, _P],
     "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "vtp_adamw": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "vtp_adamw_dev": [_P, _P, _P, _P, _P, _L, _P, _P],
+    "vtp_reduce_slabs": [_P, _L, _I, _P, _L, _I, _P],
+    "vtp_gemm_splits": [_I, _I],
+    "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],
 }
 

@@ -301,7 +301,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16* __restrict__ pb, long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2_sqrt, float gs) {
+                                                    float wd, float bc1, float bc2_sqrt, float gs,
+                                                    const float* __restrict__ hyper) {
+  if (hyper) {  // device-resident hyper-parameters: a captured hipGraph replays with fresh values every step
+    lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; gs = hyper[7];
+  }
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
     f32x4 pv = *(const f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i);
@@ -319,6 +323,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     *(f32x4*)(m + 4 * i) = mv;
     *(f32x4*)(v + 4 * i) = vv;
     if (pb) *(bf16x4*)(pb + 4 * i) = __builtin_convertvector(pv, bf16x4);
+  }
+}
+
+// dst[i] (+)= sum_s slabs[s*stride + i]   (split-K wgrad partials -> flat gradient buffer)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride, int S,
+                                                           float* __restrict__ dst, long n, int accumulate) {
+  const long n4 = n / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+    f32x4 a = accumulate ? *(const f32x4*)(dst + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) a += *(const f32x4*)(slabs + (long)s * stride + 4 * i);
+    *(f32x4*)(dst + 4 * i) = a;
   }
 }
 
@@ -450,8 +465,22 @@ extern "C" int vtp_adamw(float* p, const float* g, float* m, float* v, void* p_b
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, (const float*)nullptr);
   return check_launch("adamw");
+}
+
+extern "C" int vtp_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hyper,
+                             void* stream) {
+  VTP_REQUIRE(p && g && m && v && hyper && n > 0 && n % 4 == 0, "vtp_adamw_dev: bad argument (n %% 4 == 0)");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, 0.f,
+                     0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, hyper);
+  return check_launch("adamw_dev");
+}
+
+extern "C" int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n, int accumulate, void* stream) {
+  VTP_REQUIRE(slabs && dst && S >= 1 && n > 0 && n % 4 == 0 && stride % 4 == 0, "vtp_reduce_slabs: bad argument (n, stride %% 4 == 0)");
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4, 2048)), dim3(256), 0, (hipStream_t)stream, slabs, stride, S, dst, n, accumulate);
+  return check_launch("reduce_slabs");
 }
 
 extern "C" int vtp_ema(float* t, const float* s, long n, float momentum, void* stream) {

@@ -4,14 +4,16 @@
 // [out, in] are used as stored.  dgrad / wgrad reach this kernel through pre-transposed operands
 // (weights: cached W^T; activations: transpose kernels in elementwise.hip).
 //
-// Structure (CDNA4): 256 threads = 4 waves (2 x 2), workgroup tile BM x BN x 64, double-buffered LDS
-// filled by `global_load_lds_dwordx4` (LDS-DMA, 16 B/lane, no VGPR round trip).  The LDS image of a
-// tile is [row][64 k] bf16 (128 B rows) with the 16-byte chunk index XOR-swizzled by ((row>>1)&7) so
-// that every ds_read_b128 lane group hits 16 distinct 16-B slots (conflict-free); because LDS-DMA
-// writes lane-linear, the swizzle is applied to the per-lane *global source* address and to the read
-// address (cdna guide rule 21).  MFMA: v_mfma_f32_32x32x16_bf16 with the operands swapped (weight
-// rows feed the A operand, token rows the B operand) so that each lane ends up holding 4 consecutive
-// output columns of one output row -> 8/16-byte epilogue stores and lane-local SwiGLU / bias.
+// Structure (CDNA4): WAVES_M x WAVES_N waves, workgroup tile BM x BN x 64, a STAGES-deep LDS ring filled by
+// `global_load_lds_dwordx4` (LDS-DMA, 16 B/lane, no VGPR round trip) with *counted* `s_waitcnt vmcnt(N)` and a raw
+// `s_barrier`, so STAGES-2 further k-tiles stay in flight across the barrier while one is being multiplied.
+// The LDS image of a tile is [row][64 k] bf16 (128-B rows) with the 16-byte chunk index XOR-swizzled by
+// ((row>>1)&7) so that every ds_read_b128 lane group hits 16 distinct 16-B slots (conflict-free); LDS-DMA writes
+// lane-linear, so the swizzle is applied to the per-lane *global source* address and to the read address.
+// MFMA: v_mfma_f32_32x32x16_bf16 with the operands swapped (weight rows feed the A operand, token rows the B operand)
+// so that each lane ends up holding 4 consecutive output columns of one output row -> 8/16-byte epilogue stores and
+// lane-local SwiGLU / bias.  Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous band
+// of output rows and sweeps the weight panel (blocks b, b+8, ... run on the same XCD).
 #include "common.h"
 #include "vtp_hip.h"
 
@@ -30,12 +32,13 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldb, ldc, ldc2;
   int a_grp, a_pre;  // A row remap: row(m) = m + (m / a_grp + 1) * a_pre   (a_grp == 0: identity)
-  int c_grp, c_pre;  // C row remap (same formula)
+  int c_grp, c_pre;  // C row remap (same formula; c_grp < 0: SwiGLU de-interleave)
   int k_split;       // K elements per blockIdx.z slice (multiple of 64)
+  int xcd_swizzle;
   float alpha;
 };
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5 };
 
 __device__ __forceinline__ int remap_row(int m, int grp, int pre) {
   if (grp > 0) return m + (m / grp + 1) * pre;
@@ -43,24 +46,39 @@ __device__ __forceinline__ int remap_row(int m, int grp, int pre) {
   return m;
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int BK = 64;
-  constexpr int TM = BM / 64;  // 32-row m tiles per wave
-  constexpr int TN = BN / 64;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-  constexpr int PA = BM / 32, PB = BN / 32;  // 1-KiB LDS-DMA pieces per wave per k-tile
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per k-tile
+  constexpr int P = PA + PB;
+  static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "bad tile config");
+  static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int hi = lane >> 5;
 
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % tiles_m;
-  const int tile_n = blockIdx.x / tiles_m;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int wg = blockIdx.x;
+  if (p.xcd_swizzle) {  // bijective: XCD x (= block % 8) gets a contiguous chunk of the tile list
+    const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, x = wg & 7;
+    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+  }
+  const int tile_n = wg % tiles_n;  // n fastest: a chunk = a band of output rows x all weight panels
+  const int tile_m = wg / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.z * p.k_split;
   const int kend = min(p.K, kbeg + p.k_split);
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const char* zsrc = (const char*)g_zero_block;
 
   auto stage = [&](int buf, int kt) {
-    char* abase = smem + buf * (A_BYTES + B_BYTES);
+    char* abase = smem + buf * STAGE_BYTES;
     char* bbase = abase + A_BYTES;
     const int krem = kend - kbeg - kt * BK;  // valid k elements left in this tile (>0)
 #pragma unroll
@@ -123,12 +141,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const int sw = (lane >> 1) & 7;
   const int rowoff = (lane & 31) * 128;
 
-  if (nk > 0) stage(0, 0);
+  // prologue: STAGES-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s);
+
+  int buf = 0;  // ring slot of tile kt
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* abase = smem + (kt & 1) * (A_BYTES + B_BYTES);
+    // tile kt has landed once at most (tiles issued after it) * P of this wave's DMA pieces are still outstanding
+    const int later = min(STAGES - 2, nk - 1 - kt);
+    if (later >= 2) wait_vmcnt<2 * P>();
+    else if (later == 1) wait_vmcnt<P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; every wave finished reading tile kt-1
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, kt + STAGES - 1);  // refills the slot tile kt-1 occupied
+    }
+    const char* abase = smem + buf * STAGE_BYTES;
     const char* bbase = abase + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -136,27 +168,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       bf16x8 wf[TN], xf[TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i)
-        wf[i] = *(const bf16x8*)(bbase + (wn * (BN / 2) + i * 32) * 128 + rowoff + coff);
+        wf[i] = *(const bf16x8*)(bbase + (wn * WTN + i * 32) * 128 + rowoff + coff);
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        xf[j] = *(const bf16x8*)(abase + (wm * (BM / 2) + j * 32) * 128 + rowoff + coff);
+        xf[j] = *(const bf16x8*)(abase + (wm * WTM + j * 32) * 128 + rowoff + coff);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    if (++buf == STAGES) buf = 0;
   }
 
   // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int m = m0 + wm * (BM / 2) + j * 32 + (lane & 31);
+    const int m = m0 + wm * WTM + j * 32 + (lane & 31);
     if (m >= p.M) continue;
     const int mc = remap_row(m, p.c_grp, p.c_pre);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int nb = n0 + wn * (BN / 2) + i * 32 + 4 * hi;
+      const int nb = n0 + wn * WTN + i * 32 + 4 * hi;
       if constexpr (EPI == EPI_SWIGLU) {
         // interleaved weight rows: 16-row groups = [8 rows of w1 | 8 rows of w2]; quads (0,1) and (2,3) pair up.
 #pragma unroll
@@ -198,6 +231,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             float* c = (float*)p.C + (size_t)mc * p.ldc + n;
 #pragma unroll
             for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + e, v[e]);
+          } else if constexpr (EPI == EPI_F32_SLAB) {
+            // split-K partial: slice z writes its own [rows, ldc] slab with plain 16-B stores (no atomics);
+            // vtp_reduce_slabs sums the slabs afterwards.  slab stride (in float4 units) travels in ldc2.
+            *(f32x4*)((float*)p.C + (size_t)blockIdx.z * (size_t)p.ldc2 * 4 + (size_t)mc * p.ldc + n) = v;
           } else {
             if (p.bias) {
               f32x4 b = *(const f32x4*)(p.bias + n);
@@ -230,22 +267,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int EPI>
-static int launch_gemm(const GemmArgs& a, int splits, hipStream_t s) {
-  constexpr int LDS = 2 * (BM + BN) * 64 * 2;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
+  constexpr int LDS = STAGES * (BM + BN) * 64 * 2;
   static bool attr_set = false;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, splits);
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), grid, dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), LDS, s, a);
   return check_launch("gemm_nt");
+}
+
+// tile configurations (cfg id): 0 = 128x128 4 waves 2 stages | 1 = 128x128 4w 3 stages | 2 = 256x128 8w 2 stages |
+// 3 = 256x128 8w 3 stages | 4 = 256x256 8w 2 stages | 5 = 128x128 8w 2 stages | 6 = 128x128 4w 4 stages
+static int g_force_cfg = -1;
+static int g_xcd_swizzle = 1;
+
+template <int EPI>
+static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 1: return launch_cfg<128, 128, 2, 2, 3, EPI>(a, splits, s);
+    case 2: return launch_cfg<256, 128, 4, 2, 2, EPI>(a, splits, s);
+    case 3: return launch_cfg<256, 128, 4, 2, 3, EPI>(a, splits, s);
+    case 4: return launch_cfg<256, 256, 4, 2, 2, EPI>(a, splits, s);
+    case 5: return launch_cfg<128, 128, 4, 2, 2, EPI>(a, splits, s);
+    case 6: return launch_cfg<128, 128, 2, 2, 4, EPI>(a, splits, s);
+    default: return launch_cfg<128, 128, 2, 2, 2, EPI>(a, splits, s);
+  }
+}
+
+// measured on MI355X at the VTP-B train-step shapes (tools/gemm_bench.py, profiles/gemm_bench_r01.log)
+static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
+  if (g_force_cfg >= 0) return g_force_cfg;
+  if (M < 128 || N < 128) return 0;
+  if (splits > 1) return 3;                     // split-K wgrad: long K, few tiles -> 256x128, 3 stages
+  if (K >= 4096) return 2;                      // long-K dgrad: 256x128
+  if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
+  return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
 }
 
 }  // namespace vtp
 
 using namespace vtp;
+
+extern "C" int vtp_gemm_splits(int K, int splits) {
+  if (splits < 1) splits = 1;
+  const int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
+  return (K + ks - 1) / ks;
+}
+
+extern "C" int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle) {
+  g_force_cfg = force_cfg;
+  g_xcd_swizzle = xcd_swizzle;
+  return VTP_OK;
+}
 
 extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                            const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
@@ -256,23 +334,28 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   VTP_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "vtp_gemm_nt: N and ldc must be multiples of 4");
   VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "vtp_gemm_nt: operands must be 16-B aligned");
   VTP_REQUIRE(splits >= 1, "vtp_gemm_nt: splits must be >= 1");
-  VTP_REQUIRE(splits == 1 || epilogue == VTP_EPI_F32_ATOMIC, "vtp_gemm_nt: split-K needs the atomic epilogue");
+  VTP_REQUIRE(splits == 1 || epilogue == VTP_EPI_F32_ATOMIC || epilogue == VTP_EPI_F32_SLAB,
+              "vtp_gemm_nt: split-K needs the atomic or slab epilogue");
+  VTP_REQUIRE(epilogue != VTP_EPI_F32_SLAB || (ldc2 > 0), "vtp_gemm_nt: slab epilogue needs ldc2 = slab stride / 4 (in float4 units)");
   GemmArgs a;
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = C2; a.bias = bias; a.gamma = gamma; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = alpha;
+  a.xcd_swizzle = g_xcd_swizzle;
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
   hipStream_t s = (hipStream_t)stream;
+  const int cfg = pick_cfg(M, N, K, epilogue, splits);
   switch (epilogue) {
-    case VTP_EPI_BF16: return launch_gemm<128, 128, EPI_BF16>(a, 1, s);
-    case VTP_EPI_F32: return launch_gemm<128, 128, EPI_F32>(a, 1, s);
+    case VTP_EPI_BF16: return launch_gemm<EPI_BF16>(a, 1, cfg, s);
+    case VTP_EPI_F32: return launch_gemm<EPI_F32>(a, 1, cfg, s);
     case VTP_EPI_SWIGLU:
       VTP_REQUIRE(N % 16 == 0 && bias, "vtp_gemm_nt: SwiGLU epilogue needs interleaved N %% 16 == 0 and a bias");
-      return launch_gemm<128, 128, EPI_SWIGLU>(a, 1, s);
-    case VTP_EPI_GELU: return launch_gemm<128, 128, EPI_GELU>(a, 1, s);
-    case VTP_EPI_F32_ATOMIC: return launch_gemm<128, 128, EPI_F32_ATOMIC>(a, splits, s);
+      return launch_gemm<EPI_SWIGLU>(a, 1, cfg, s);
+    case VTP_EPI_GELU: return launch_gemm<EPI_GELU>(a, 1, cfg, s);
+    case VTP_EPI_F32_ATOMIC: return launch_gemm<EPI_F32_ATOMIC>(a, splits, cfg, s);
+    case VTP_EPI_F32_SLAB: return launch_gemm<EPI_F32_SLAB>(a, splits, cfg, s);
     default: VTP_REQUIRE(false, "vtp_gemm_nt: unknown epilogue %d", epilogue);
   }
   return VTP_OK;

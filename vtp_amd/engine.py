@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .ops import EPI_BF16, EPI_F32, EPI_F32_ATOMIC, EPI_GELU, EPI_SWIGLU, pad8
+from .ops import EPI_BF16, EPI_F32, EPI_F32_SLAB, EPI_GELU, EPI_SWIGLU, pad8
 
 
 # =====================================================================================================================
@@ -200,17 +200,45 @@ class Workspace:
 BF, F32 = torch.bfloat16, torch.float32
 
 
+class Overlap:
+    """Side HIP stream for the weight-gradient branch of every linear backward: dW (transposes + split-K GEMM + slab
+    reduce) is independent of dX, so it runs concurrently with the dgrad GEMM and fills the CUs that the other kernel's
+    tail leaves idle.  fork/join are event waits (captured as parallel hipGraph branches under stream capture)."""
+
+    enabled = True
+
+    def __init__(self):
+        self.side = None
+
+    def _side(self):
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        return self.side
+
+    def fork(self):
+        self._side().wait_stream(torch.cuda.current_stream())
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+OVERLAP = Overlap()
+
+
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
+    """Split-K factor for a wgrad GEMM (output [n_rows, n_cols], reduction over k tokens): enough workgroups to fill
+    256 CUs (~384 tiles), each slice keeping >= 8 k-tiles."""
     tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
-    s = max(1, min(round(768 / tiles), k // 256, 64))
-    return int(s)
+    return int(max(1, min(round(384 / tiles), k // 512, 16)))
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
                x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0):
     """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
-    column sums for db ride along), W^T is the cached transposed weight."""
+    column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
+    dimension; slices write private fp32 slabs (plain stores) that one reduce kernel folds into the flat gradient."""
     N = L.N if N is None else N
     K = L.K if K is None else K
     gw = L.gw if gw is None else gw
@@ -219,10 +247,29 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
     Mp = pad8(M)
     dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
     xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
-    ops.transpose_bf16(dy_b, dy_b.stride(0), dyT, Mp, M, N, colsum=gb, swiglu_h=swiglu_h, in_remap=dy_remap)
-    ops.transpose_bf16(x_b, x_b.stride(0), xT, Mp, M, K, in_remap=x_remap)
-    ops.gemm_nt(dyT, xT, gw, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, epi=EPI_F32_ATOMIC, splits=_wgrad_splits(N, K, Mp),
-                c_remap=(-1, swiglu_h) if swiglu_h else (0, 0))
+    c_remap = (-1, swiglu_h) if swiglu_h else (0, 0)
+    S = ops.gemm_splits(Mp, _wgrad_splits(N, K, Mp))
+
+    def wgrad():
+        ops.transpose_bf16(dy_b, dy_b.stride(0), dyT, Mp, M, N, colsum=gb, swiglu_h=swiglu_h, in_remap=dy_remap)
+        ops.transpose_bf16(x_b, x_b.stride(0), xT, Mp, M, K, in_remap=x_remap)
+        if S == 1:
+            ops.gemm_nt(dyT, xT, gw, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, resid=gw, epi=EPI_F32, c_remap=c_remap)
+        else:
+            n_el = N * K
+            slab = ws.get("T.slab", (S * n_el,), F32)
+            ops.gemm_nt(dyT, xT, slab, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, ldc2=n_el // 4, epi=EPI_F32_SLAB, splits=S,
+                        c_remap=c_remap)
+            ops.reduce_slabs(slab, n_el, S, gw, n_el, accumulate=True)
+
+    if OVERLAP.enabled and need_dx:
+        OVERLAP.join()   # previous layer's dW branch is done with the shared T.* scratch (and with its inputs)
+        OVERLAP.fork()   # the side stream sees dy_b / x_b complete
+        with torch.cuda.stream(OVERLAP.side):
+            wgrad()
+    else:
+        OVERLAP.join()
+        wgrad()
     if need_dx:
         ops.gemm_nt(dy_b, wT, d_in, M=M, N=K, K=N, lda=dy_b.stride(0), ldb=N, ldc=d_in.stride(0), epi=EPI_BF16,
                     a_remap=dy_remap, c_remap=dx_remap)
@@ -294,7 +341,9 @@ class Stack:
         return x
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
-    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, block_hook=None):
+    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int):
+        """Generator: yields the block index i each time all parameter gradients of block i have been enqueued (a
+        gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input."""
         D, H, heads = self.D, self.H, self.heads
         M = B * N
         scale = 1.0 / math.sqrt(64.0)
@@ -327,8 +376,8 @@ class Stack:
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
             ops.norm_bwd(dxn, b.x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
             dy, dy_b = dxo, dxo_b
-            if block_hook is not None:
-                block_hook(i)  # all parameter gradients of block i are enqueued
+            OVERLAP.join()
+            yield ("block", i)
         return dy, dy_b
 
 
@@ -369,7 +418,7 @@ class TrunkEngine:
         self.H = swiglu_hidden(self.D, cfg.vision_mlp_ratio)
         self.kind = ops.NORM_RMS if cfg.vision_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
-        self.periods = periods
+        self.periods = periods.detach().to("cpu")  # host copy: rope_tables must not touch the device during graph capture
         self.pe = store.lin("trunk.patch_embed.proj.weight", "trunk.patch_embed.proj.bias", self.D, 768, need_T=False)
         self.stack = Stack(store, "trunk.blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
         self.bott_dim = cfg.vision_feature_bottleneck
@@ -414,8 +463,9 @@ class TrunkEngine:
                     a_remap=(hw, 1))
         return lat
 
-    def backward(self, d_lat: Optional[torch.Tensor], after_tail=None, block_hook=None):
-        """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g."""
+    def backward(self, d_lat: Optional[torch.Tensor]):
+        """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g.
+        Generator (see Stack.backward): yields "tail", then ("block", i) per block."""
         st = self.store
         ws, B, h, w, xl, xnf, stf, rope, patches, masks = self._ctx
         assert masks is None, "mask-token backward is not implemented yet"
@@ -428,12 +478,13 @@ class TrunkEngine:
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, xl, st.p("trunk.norm.weight"), stf, None, dx, dx_b, st.g("trunk.norm.weight"),
                      st.g("trunk.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
-        if after_tail is not None:
-            after_tail()
-        dx0, dx0_b = self.stack.backward(ws, dx, dx_b, B, N, rope, 1, block_hook)
+        OVERLAP.join()
+        yield "tail"
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, N, rope, 1)
         # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
         linear_bwd(ws, "pe", self.pe, dx0_b, patches, B * hw, None, need_dx=False, dy_remap=(hw, 1))
         ops.strided_rowsum(dx0, N * D, st.g("trunk.cls_token"), B, D)
+        OVERLAP.join()
 
 
 # =====================================================================================================================
@@ -447,7 +498,7 @@ class DecoderEngine:
         self.H = swiglu_hidden(self.D, 4.0)
         self.kind = ops.NORM_RMS if cfg.decoder_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
-        self.periods = periods
+        self.periods = periods.detach().to("cpu")
         self.cin = cfg.vision_feature_bottleneck
         self.pin = store.lin("pixel_decoder.proj_in.weight", "pixel_decoder.proj_in.bias", self.D, self.cin)
         self.stack = Stack(store, "pixel_decoder.blocks.", self.depth, self.D, self.heads, self.H, cfg.decoder_norm_layer)
@@ -478,8 +529,9 @@ class DecoderEngine:
         self._ctx = (ws, B, h, w, lat, xl, xnf, stf, rope)
         return t
 
-    def backward(self, dt: torch.Tensor, after_tail=None, block_hook=None) -> torch.Tensor:
-        """dt bf16 [B*hw, 768] -> d_lat bf16 [B*hw, 64]; parameter grads accumulate into store.flat_g."""
+    def backward(self, dt: torch.Tensor):
+        """dt bf16 [B*hw, 768] -> d_lat bf16 [B*hw, 64]; parameter grads accumulate into store.flat_g.
+        Generator: yields "tail", then ("block", i) per block; returns d_lat."""
         st = self.store
         ws, B, h, w, lat, xl, xnf, stf, rope = self._ctx
         M, D = B * h * w, self.D
@@ -489,9 +541,10 @@ class DecoderEngine:
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, xl, st.p("pixel_decoder.norm.weight"), stf, None, dx, dx_b, st.g("pixel_decoder.norm.weight"),
                      st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
-        if after_tail is not None:
-            after_tail()
-        dx0, dx0_b = self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, block_hook)
+        OVERLAP.join()
+        yield "tail"
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0)
         d_lat = ws.get("b.d_lat", (M, self.cin), BF)
         linear_bwd(ws, "pin", self.pin, dx0_b, lat, M, d_lat)
+        OVERLAP.join()
         return d_lat

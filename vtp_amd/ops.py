@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 
-EPI_BF16, EPI_F32, EPI_SWIGLU, EPI_GELU, EPI_F32_ATOMIC = 0, 1, 2, 3, 4
+EPI_BF16, EPI_F32, EPI_SWIGLU, EPI_GELU, EPI_F32_ATOMIC, EPI_F32_SLAB = 0, 1, 2, 3, 4, 5
 NORM_RMS, NORM_LN = 0, 1
 
 
@@ -114,6 +114,18 @@ def l1_loss_fwd_bwd(t, target, dt, loss_sum, B, h, w, gscale):
 def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     _lib.check(_lib_().vtp_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, lr, beta1, beta2, eps, wd, step, grad_scale,
                                  _s()), "vtp_adamw")
+
+
+def adamw_dev(p, g, m, v, p_bf16, n, hyper):
+    _lib.check(_lib_().vtp_adamw_dev(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _s()), "vtp_adamw_dev")
+
+
+def gemm_splits(K, splits):
+    return _lib_().vtp_gemm_splits(K, splits)
+
+
+def reduce_slabs(slabs, stride, S, dst, n, accumulate=True):
+    _lib.check(_lib_().vtp_reduce_slabs(_p(slabs), stride, S, _p(dst), n, int(accumulate), _s()), "vtp_reduce_slabs")
 
 
 def ema(t, s, n, momentum):

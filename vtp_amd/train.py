@@ -74,7 +74,7 @@ class VTPTrainer:
     """Reconstruction-path trainer (BASELINE config 2 and the `rec` third of config 3)."""
 
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
-                 group=None, bucket_blocks: int = 3):
+                 group=None, bucket_blocks: int = 3, use_graphs: bool = False):
         self.model = model
         self.store = model._engine()
         self.trunk, self.decoder = model._trunk, model._decoder
@@ -92,6 +92,11 @@ class VTPTrainer:
         self.world = self.bucketer.world
         self.bucket_blocks = bucket_blocks
         self._bucket_plan = self._plan_buckets()
+        # hyper-parameters live in device memory so that captured hipGraphs replay with per-step values
+        self.hyper = torch.zeros(8, dtype=F32, device=st.device)
+        self._hyper_host = torch.zeros(8, dtype=F32).pin_memory()
+        self.use_graphs = use_graphs
+        self._graphs = {}
 
     # gradient buckets in backward-completion order: decoder tail, decoder blocks (high->low), trunk blocks, trunk head
     def _plan_buckets(self):
@@ -104,30 +109,39 @@ class VTPTrainer:
                 "dec_head": rng("pixel_decoder.proj_in."),
                 "trunk_tail": rng("trunk.norm.") + rng("trunk.feature_bottleneck."),
                 "trunk_head": rng("trunk.cls_token") + rng("trunk.mask_token") + rng("trunk.patch_embed.")}
-        for tower, depth in (("pixel_decoder", self.decoder.depth), ("trunk", self.trunk.depth)):
+        for key, tower, depth in (("dec", "pixel_decoder", self.decoder.depth), ("trunk", "trunk", self.trunk.depth)):
             for i in range(depth):
-                plan[f"{tower}.{i}"] = rng(f"{tower}.blocks.{i}.")
+                plan[f"{key}.{i}"] = rng(f"{tower}.blocks.{i}.")
         return plan
 
     def _reduce(self, keys: Sequence[str]):
-        if self.world == 1:
+        if self.world == 1 or not keys:
             return
         rs = merge_ranges([r for k in keys for r in self._bucket_plan[k]])
         for lo, hi in rs:
             self.bucketer.reduce_range(lo, hi)
 
-    def _block_hook(self, tower: str, depth: int) -> Callable[[int], None]:
+    # ------------------------------------------------------------------------------------------------------------
+    # The step is written ONCE as a generator.  Every `yield keys` is a point where the gradients of the parameter
+    # groups `keys` are complete: the eager driver launches their RCCL all-reduce there; the graph driver ends a
+    # hipGraph segment there (collectives stay outside the graphs, between segment launches).
+    # ------------------------------------------------------------------------------------------------------------
+    def _tower_backward(self, tower: str, gen, depth: int):
         nb = self.bucket_blocks
+        result = None
+        try:
+            while True:
+                ev = next(gen)
+                if ev == "tail":
+                    yield [f"{tower}_tail"]
+                elif ev[0] == "block" and ev[1] % nb == 0:
+                    i = ev[1]
+                    yield [f"{tower}.{j}" for j in range(i, min(i + nb, depth))]
+        except StopIteration as stop:
+            result = stop.value
+        return result
 
-        def hook(i: int):
-            # block i just finished its backward: flush a bucket every `nb` blocks (and at block 0)
-            if i % nb == 0:
-                self._reduce([f"{tower}.{j}" for j in range(i, min(i + nb, depth))])
-        return hook
-
-    def step_rec(self, images: torch.Tensor) -> torch.Tensor:
-        """One optimizer step on the L1 reconstruction loss.  images: f32 [B,3,H,W] on the device.
-        Returns the (local) loss as a device scalar tensor (no host sync)."""
+    def _step_gen(self, images: torch.Tensor):
         st = self.store
         B, _, H, W = images.shape
         h, w = H // 16, W // 16
@@ -138,21 +152,87 @@ class VTPTrainer:
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
         ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, 1.0 / (B * 3 * H * W))
-        d_lat = self.decoder.backward(dt, after_tail=lambda: self._reduce(["dec_tail"]),
-                                      block_hook=self._block_hook("pixel_decoder", self.decoder.depth))
-        self._reduce(["dec_head"])
-        self.trunk.backward(d_lat, after_tail=lambda: self._reduce(["trunk_tail"]),
-                            block_hook=self._block_hook("trunk", self.trunk.depth))
-        self._reduce(["trunk_head"])
-        self.bucketer.wait()
-        self.optimizer_step()
+        d_lat = yield from self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
+        yield ["dec_head"]
+        yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
+        yield ["trunk_head"]
+        # ---- optimizer (after every bucket has been reduced)
+        for lo, hi in self.ranges:
+            ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
+        st.prep()
+
+    def _set_hyper(self):
+        self.step_no += 1
+        b1, b2 = self.betas
+        vals = [self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.step_no, (1.0 - b2 ** self.step_no) ** 0.5,
+                1.0 / self.world]
+        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def step_rec(self, images: torch.Tensor) -> torch.Tensor:
+        """One optimizer step on the L1 reconstruction loss.  images: f32 [B,3,H,W] on the device.
+        Returns the (local) loss as a device scalar tensor (no host sync)."""
+        B, _, H, W = images.shape
+        self._set_hyper()
+        if self.use_graphs:
+            self._step_graphs(images)
+        else:
+            gen = self._step_gen(images)
+            pending_wait = False
+            for keys in gen:
+                if keys == ["trunk_head"]:
+                    self._reduce(keys)
+                    self.bucketer.wait()  # the generator's next (last) leg is the optimizer
+                    pending_wait = True
+                else:
+                    self._reduce(keys)
+            assert pending_wait
+        self.model._pver = self.model._param_version()
         return self.loss_sum / float(B * 3 * H * W)
 
-    def optimizer_step(self):
-        st = self.store
-        self.step_no += 1
-        for lo, hi in self.ranges:
-            ops.adamw(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.wd, self.step_no, 1.0 / self.world)
-        st.prep()
-        self.model._pver = self.model._param_version()
+    # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
+    def _step_graphs(self, images: torch.Tensor):
+        key = tuple(images.shape)
+        plan = self._graphs.get(key)
+        if plan is None:
+            # warm-up in eager mode on a side stream (allocates every workspace buffer, sets kernel attributes)
+            static_img = torch.empty_like(images)
+            static_img.copy_(images)
+            snap = (self.store.flat_p.clone(), self.m.clone(), self.v.clone())
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in self._step_gen(static_img):
+                    pass
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            # the warm-up performed a real (local, un-reduced) optimizer step: roll parameters and moments back
+            st = self.store
+            st.flat_p.copy_(snap[0])
+            self.m.copy_(snap[1])
+            self.v.copy_(snap[2])
+            st.prep()
+            del snap
+            segs = []
+            pool = torch.cuda.graph_pool_handle()
+            gen = self._step_gen(static_img)
+            done = False
+            while not done:
+                g = torch.cuda.CUDAGraph()
+                keys = None
+                with torch.cuda.graph(g, pool=pool):
+                    try:
+                        keys = next(gen)
+                    except StopIteration:
+                        done = True
+                segs.append((g, keys))
+            plan = (static_img, segs)
+            self._graphs[key] = plan
+        static_img, segs = plan
+        static_img.copy_(images)
+        for g, keys in segs:
+            g.replay()
+            if keys is not None:
+                self._reduce(keys)
+                if keys == ["trunk_head"]:
+                    self.bucketer.wait()
