@@ -32,12 +32,31 @@ import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0
 
+_SMALL = dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_embed_dim=384, text_depth=12,
+              text_num_heads=6, decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6)
 WORKLOADS = {
-    # name: (config kwargs, per-GPU batch, resolution)
-    "vtp_base_rec": (dict(), 32, 256),
-    "vtp_small_rec": (dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_embed_dim=384, text_depth=12,
-                           text_num_heads=6, decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6), 64, 256),
+    # name: (config kwargs, per-GPU batch, resolution, objectives)
+    "vtp_base_rec_clip": (dict(), 32, 256, ("rec", "clip")),   # BASELINE config 3 minus the SSL head (not built yet)
+    "vtp_base_rec": (dict(), 32, 256, ("rec",)),
+    "vtp_small_rec": (_SMALL, 64, 256, ("rec",)),               # BASELINE config 2
 }
+
+
+def synthetic_captions(B, T, vocab, device, seed):
+    """ids ~ U{1..vocab-3}, SOT = vocab-2 first, EOT = vocab-1 at a random length in [8, T-1], zeros after
+    (so the argmax pooling of text_transformer.py:222-224 hits EOT)."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, vocab - 2, (B, T), generator=g)
+    ids[:, 0] = vocab - 2
+    ln = torch.randint(8, T, (B,), generator=g)
+    ar = torch.arange(T)[None, :]
+    ids = torch.where(ar < ln[:, None], ids, torch.zeros_like(ids))
+    ids[torch.arange(B), ln] = vocab - 1
+    return ids.to(device)
+
+
+def text_fwd_gflop(D, L, T):
+    return (L * (2 * T * 12 * D * D + 4 * T * T * D) + 2 * D * D) / 1e9
 
 
 def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
@@ -50,22 +69,27 @@ def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
     return f / 1e9
 
 
-def cpu_baseline(model, B_cpu, res, budget_s=20.0):
-    """The CPU oracle timed on the host: same rec train step (fwd + L1 + autograd bwd + AdamW), fp32, all cores."""
+def cpu_baseline(model, B_cpu, res, clip, budget_s=20.0):
+    """The CPU oracle timed on the host: same train step (fwd + losses + autograd bwd + AdamW), fp32, all cores."""
     from oracle import vtp_oracle as O
     cfg = model.config
     sd = {k: v.detach().float().cpu().clone() if v.dtype == torch.float32 else v.detach().cpu().clone()
           for k, v in model.state_dict().items()}
-    keys = [k for k in sd if (k.startswith("trunk.") or k.startswith("pixel_decoder.")) and sd[k].dtype == torch.float32]
+    keys = [k for k in sd if sd[k].dtype == torch.float32 and (clip or k.startswith("trunk.") or k.startswith("pixel_decoder."))]
     for k in keys:
         sd[k].requires_grad_(True)
     opt = torch.optim.AdamW([sd[k] for k in keys], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
     img = torch.randn(B_cpu, 3, res, res, generator=torch.Generator().manual_seed(99))
+    txt = synthetic_captions(B_cpu, cfg.text_context_length, cfg.text_vocab_size, "cpu", 98)
     n_thr = torch.get_num_threads()
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = O.rec_train_loss(sd, img, cfg.vision_num_heads, cfg.decoder_num_heads)
+        if clip:
+            l1, lc = O.rec_clip_train_loss(sd, img, txt, cfg.vision_num_heads, cfg.decoder_num_heads, cfg.text_num_heads)
+            loss = l1 + lc
+        else:
+            loss = O.rec_train_loss(sd, img, cfg.vision_num_heads, cfg.decoder_num_heads)
         loss.backward()
         opt.step()
 
@@ -79,7 +103,8 @@ def cpu_baseline(model, B_cpu, res, budget_s=20.0):
             break
     dt = time.perf_counter() - t0
     return {"value": round(n * B_cpu / dt, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(),
-            "kind": "port", "sample": f"{n} fp32 train steps (fwd+L1+bwd+AdamW) of the same model at batch {B_cpu} after 1 warm-up"}
+            "kind": "port", "sample": f"{n} fp32 train steps (fwd + {'L1+CLIP' if clip else 'L1'} loss + bwd + AdamW) of the same model "
+                                      f"at batch {B_cpu} after 1 warm-up"}
 
 
 def main():
@@ -87,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vtp_base_rec", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="vtp_base_rec_clip", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -109,12 +134,14 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from vtp_amd import VTPConfig, VTPModel, VTPTrainer, ops
-    cfg_kw, B, res = WORKLOADS[args.workload]
+    cfg_kw, B, res, objectives = WORKLOADS[args.workload]
+    clip = "clip" in objectives
     B = args.batch or B
     torch.manual_seed(0)
     model = VTPModel(VTPConfig(**cfg_kw)).to(dev)
     trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs)
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+    txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
 
     def sync():
         if world > 1:
@@ -122,18 +149,18 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step_rec(img)
+        trainer.step(img, txt)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step_rec(img)
+        loss, closs = trainer.step(img, txt)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_val, closs_val = float(loss), float(closs)
 
     # ---- dominant-kernel roofline: one instrumented step, HIP events around every gemm_nt launch (rank 0)
     roof = None
@@ -155,7 +182,7 @@ def main():
         ops.gemm_nt = timed_gemm
         trainer.use_graphs = False  # the instrumented step launches eagerly (events cannot sit inside a replayed graph)
         try:
-            trainer.step_rec(img)
+            trainer.step(img, txt)
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt = orig
@@ -175,27 +202,32 @@ def main():
     from vtp_amd.config import swiglu_hidden
     enc = vit_fwd_gflop(c.vision_embed_dim, swiglu_hidden(c.vision_embed_dim), c.vision_depth, hw + 1, hw, True)
     dec = vit_fwd_gflop(c.decoder_embed_dim, swiglu_hidden(c.decoder_embed_dim), c.decoder_depth, hw, hw, False)
-    gflop_img = 3.0 * (enc + dec)
+    tflop = text_fwd_gflop(c.text_embed_dim, c.text_depth, c.text_context_length) if clip else 0.0
+    gflop_img = 3.0 * (enc + dec + tflop)            # executed: one shared trunk pass serves rec and clip
+    gflop_ref = 3.0 * (enc + dec) + (3.0 * (enc + tflop) if clip else 0.0)  # BASELINE.md accounting (separate passes)
     ips = world * B * args.steps / elapsed
     out = {
-        "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload == "vtp_base_rec"
+        "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload.startswith("vtp_base")
         else "images/sec/node VTP-S f16d64 256x256 train step",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: full optimizer step (fwd + L1 recon loss + bwd + grad all-reduce + AdamW) "
-                               f"of VTPModel trunk+pixel_decoder, {B} img/GPU @ {res}x{res}, random-init weights; "
-                               "contrastive + SSL heads of config 3 not yet in the step",
+        "config": {"workload": f"{args.workload}: full optimizer step (fwd + {'L1 recon + CLIP contrastive' if clip else 'L1 recon'} "
+                               f"loss + bwd + grad all-reduce{' + feature all-gather/reduce-scatter' if clip else ''} + AdamW) of VTPModel "
+                               f"trunk + pixel_decoder{' + text tower' if clip else ''}, {B} img/GPU @ {res}x{res}"
+                               f"{', 77-token synthetic captions' if clip else ''}, random-init weights; the SSL (DINO/iBOT) "
+                               "head of BASELINE config 3 is not built yet",
                    "launch": "eager" if args.no_graphs else "hipGraph segments", "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
-                   "train_gflop_per_image": round(gflop_img, 1)},
-        "loss": round(loss_val, 5),
+                   "train_gflop_per_image": round(gflop_img, 1),
+                   "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5),
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
     if rank == 0:
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res)
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res, clip)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -132,6 +132,29 @@ int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n,
 /* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
 int vtp_ema(float* t, const float* s, long n, float momentum, void* stream);
 
+/* ---- CLIP text-tower glue + contrastive head (fp32; clip.hip) -------------------------------------------------
+ * embed: x f32 [B*T, D] = table[ids] + pos (modeling_vtp.py:296-297); eot[b] = argmax_t ids[b,t] (text_global_pool
+ * 'argmax', text_transformer.py:222-224).  ids are int64 [B, T].  bwd: d_table[ids] += dx (atomics), d_pos += sum_b dx. */
+int vtp_embed_tokens(const long* ids, const float* table, const float* pos, float* x, int* eot, int B, int T, int D,
+                     void* stream);
+int vtp_embed_tokens_bwd(const long* ids, const float* dx, float* d_table, float* d_pos, int B, int T, int D, void* stream);
+/* out f32 [B, D] = x[b*T + idx[b]] ; scatter: dx f32 [B*T, D] (and optional bf16 copy) = 0 except those rows = dy. */
+int vtp_gather_rows(const float* x, const int* idx, float* out, int B, int T, int D, void* stream);
+int vtp_scatter_rows(const float* dy, const int* idx, float* dx, void* dx_bf16, int B, int T, int D, void* stream);
+/* F.normalize(x, dim=-1, eps) (modeling_vtp.py:276,310): y = x * inv_norm, inv_norm = 1 / max(||x||, eps); and its backward. */
+int vtp_l2norm_fwd(const float* x, float* y, float* inv_norm, int B, int D, float eps, void* stream);
+int vtp_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B, int D, void* stream);
+/* Contrastive loss (OpenCLIP ClipLoss, local_loss + gather_with_grad convention; NOT in the reference -> parity unpinned):
+ *   logits_i2t = exp(ls) * img_local @ txt_all^T, logits_t2i = exp(ls) * txt_local @ img_all^T  (modeling_vtp.py:329),
+ *   labels = label_offset + arange(B_local); loss_sum += 0.5 * (mean CE_i2t + mean CE_t2i).
+ * Outputs (overwritten): d_img_local, d_txt_local [B_local, D]; d_img_all, d_txt_all [B_all, D] = the gradient this rank
+ * contributes to EVERY rank's features (reduce-scatter them across ranks and add the local slice); d_logit_scale[0] +=
+ * dL/d(logit_scale).  scratch: 2 * B_local * B_all floats.  All features f32, L2-normalised by the caller. */
+int vtp_clip_loss(const float* img_local, const float* txt_local, const float* img_all, const float* txt_all,
+                  const float* logit_scale, int B_local, int B_all, int D, int label_offset, float* loss_sum,
+                  float* d_img_local, float* d_txt_local, float* d_img_all, float* d_txt_all, float* d_logit_scale,
+                  float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

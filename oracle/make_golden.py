@@ -17,6 +17,14 @@ from safetensors.torch import save_file
 
 from oracle.ref_stubs import TINY, load_reference
 
+GRAD2_KEYS = [  # gradients of (L1 + CLIP) -- the backward through the text tower / heads is the reference's autograd
+    "logit_scale", "visual_proj.weight", "text_projection", "ln_final.weight", "ln_final.bias", "positional_embedding",
+    "token_embedding.weight", "text_transformer.resblocks.0.attn.in_proj_weight", "text_transformer.resblocks.0.attn.in_proj_bias",
+    "text_transformer.resblocks.1.attn.out_proj.weight", "text_transformer.resblocks.0.mlp.c_fc.weight",
+    "text_transformer.resblocks.1.mlp.c_proj.bias", "text_transformer.resblocks.1.ln_2.weight",
+    "trunk.cls_token", "trunk.blocks.1.attn.qkv.weight", "trunk.norm.weight", "trunk.patch_embed.proj.weight",
+]
+
 GRAD_KEYS = [
     "trunk.patch_embed.proj.weight", "trunk.cls_token", "trunk.blocks.0.attn.qkv.weight",
     "trunk.blocks.0.attn.qkv.bias", "trunk.blocks.1.mlp.w1.weight", "trunk.blocks.1.mlp.w3.bias",
@@ -72,6 +80,18 @@ def main(out_path: str):
     params = dict(model.named_parameters())
     for k in GRAD_KEYS:
         out["grad." + k] = params[k].grad.detach().clone().contiguous()
+    # L1 + CLIP (OpenCLIP ClipLoss on the reference's own 'clip' forward outputs); loss spec is ours, backward is the reference's
+    model.zero_grad()
+    r = model(image=img, forward_type="rec")
+    l1 = (r["reconstructed_image"] - r["target_image"]).abs().mean()
+    c = model(image=img, text=text, forward_type="clip")
+    logits = c["logit_scale"] * c["image_features"] @ c["text_features"].T
+    labels = torch.arange(logits.shape[0])
+    lclip = 0.5 * (torch.nn.functional.cross_entropy(logits, labels) + torch.nn.functional.cross_entropy(logits.T, labels))
+    (l1 + lclip).backward()
+    out["out.clip_loss"] = lclip.detach().reshape(1)
+    for k in GRAD2_KEYS:
+        out["grad2." + k] = params[k].grad.detach().clone().contiguous()
     for k, v in model.state_dict().items():
         out["sd." + k] = v.detach().clone().contiguous()
     save_file(out, out_path)

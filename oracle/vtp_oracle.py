@@ -264,6 +264,16 @@ def rec_train_loss(sd, img, vis_heads, dec_heads) -> Tensor:
     return l1_loss(rec, img)
 
 
+def rec_clip_train_loss(sd, img, text, vis_heads, dec_heads, txt_heads) -> Tuple[Tensor, Tensor]:
+    """rec (L1) + clip (InfoNCE) on the same images: returns (l1, clip).  The trunk is evaluated once per objective
+    exactly like two VTP.forward calls (forward_type='rec' and 'clip', vtp.py:323-338); with drop rates 0 both see the
+    same trunk activations."""
+    l1 = rec_train_loss(sd, img, vis_heads, dec_heads)
+    i = clip_image_feature(sd, img, vis_heads)
+    t = clip_text_feature(sd, text, txt_heads)
+    return l1, clip_loss(i, t, sd["logit_scale"].exp())
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, b1: float, b2: float,
                eps: float, wd: float) -> None:
     """torch.optim.AdamW semantics (decoupled weight decay), in place, fp32."""

@@ -399,3 +399,89 @@ def test_c_abi_rejects_bad_arguments():
         o.gemm_nt(a, a, c)
     with pytest.raises(RuntimeError, match="prefix"):
         o.rope_qk(c, c, c, 1, 4, 1, 9)
+
+
+# ----------------------------------------------------------------------------------------------------------- CLIP head
+def test_text_glue_kernels():
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    B, T, D, V = 5, 16, 128, 300
+    ids = torch.randint(1, V - 1, (B, T), device=DEV, generator=g)
+    eot_pos = torch.tensor([3, 15, 7, 1, 9], device=DEV)
+    ids[torch.arange(B), eot_pos] = V - 1
+    table = torch.randn(V, D, device=DEV, generator=g)
+    pos = torch.randn(T, D, device=DEV, generator=g)
+    x = torch.empty(B * T, D, device=DEV)
+    eot = torch.empty(B, dtype=torch.int32, device=DEV)
+    o.embed_tokens(ids, table, pos, x, eot, B, T, D)
+    assert torch.equal(x.view(B, T, D), table[ids] + pos)
+    assert torch.equal(eot.long(), ids.argmax(-1)) and torch.equal(eot.long(), eot_pos)
+    pooled = torch.empty(B, D, device=DEV)
+    o.gather_rows(x, eot, pooled, B, T, D)
+    assert torch.equal(pooled, x.view(B, T, D)[torch.arange(B), eot_pos])
+    dy = torch.randn(B, D, device=DEV, generator=g)
+    dx = torch.full((B * T, D), float("nan"), device=DEV)
+    dxb = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.scatter_rows(dy, eot, dx, dxb, B, T, D)
+    ref = torch.zeros(B, T, D, device=DEV)
+    ref[torch.arange(B), eot_pos] = dy
+    assert torch.equal(dx.view(B, T, D), ref) and torch.equal(dxb.view(B, T, D), bf(ref))
+    dxx = torch.randn(B * T, D, device=DEV, generator=g)
+    d_table = torch.zeros(V, D, device=DEV)
+    d_pos = torch.ones(T, D, device=DEV)
+    o.embed_tokens_bwd(ids, dxx, d_table, d_pos, B, T, D)
+    ref_t = torch.zeros(V, D, device=DEV).index_add_(0, ids.reshape(-1), dxx)
+    check(d_table, ref_t, "embed bwd table", bf16_out=False, scale=1e-6)
+    check(d_pos, 1 + dxx.view(B, T, D).sum(0), "embed bwd pos", bf16_out=False, scale=1e-6)
+    xx = torch.randn(B, D, device=DEV, generator=g) * 3
+    y = torch.empty_like(xx)
+    inv = torch.empty(B, device=DEV)
+    o.l2norm_fwd(xx, y, inv, B, D)
+    xr = xx.clone().requires_grad_(True)
+    yr = F.normalize(xr, dim=-1)
+    check(y, yr.detach(), "l2norm fwd", bf16_out=False, scale=1e-6)
+    gy = torch.randn(B, D, device=DEV, generator=g)
+    yr.backward(gy)
+    dxo = torch.empty_like(xx)
+    o.l2norm_bwd(gy, y, inv, dxo, B, D)
+    check(dxo, xr.grad, "l2norm bwd", bf16_out=False, scale=1e-5)
+
+
+@pytest.mark.parametrize("world,Bl,D", [(1, 6, 128), (2, 4, 128), (4, 32, 768)])
+def test_clip_loss_with_emulated_ranks(world, Bl, D):
+    """Every 'rank' runs vtp_clip_loss on its local rows against the gathered features; the total feature gradient of
+    rank r = d_local(r) + sum_r' d_all(r')[rows of r]  must equal autograd of sum_r' L_r' (DDP then averages the
+    parameter gradients), and sum_r loss_r / world the OpenCLIP global loss."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(world * 100 + Bl)
+    Bg = world * Bl
+    I = F.normalize(torch.randn(Bg, D, device=DEV, generator=g), dim=-1)
+    T = F.normalize(torch.randn(Bg, D, device=DEV, generator=g) + 0.5 * I, dim=-1)
+    ls = torch.tensor([2.0], device=DEV)
+    Ir, Tr, lsr = I.clone().requires_grad_(True), T.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    total = 0.0
+    for r in range(world):
+        sl = slice(r * Bl, (r + 1) * Bl)
+        labels = torch.arange(r * Bl, (r + 1) * Bl, device=DEV)
+        li = lsr.exp() * Ir[sl] @ Tr.T
+        lt = lsr.exp() * Tr[sl] @ Ir.T
+        total = total + 0.5 * (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels))
+    total.backward()
+    dI = torch.zeros_like(I)
+    dT = torch.zeros_like(T)
+    dls = torch.zeros(1, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    for r in range(world):
+        sl = slice(r * Bl, (r + 1) * Bl)
+        d_il, d_tl = torch.empty(Bl, D, device=DEV), torch.empty(Bl, D, device=DEV)
+        d_ia, d_ta = torch.empty(Bg, D, device=DEV), torch.empty(Bg, D, device=DEV)
+        scratch = torch.empty(2 * Bl * Bg, device=DEV)
+        o.clip_loss(I[sl].contiguous(), T[sl].contiguous(), I, T, ls, Bl, Bg, D, r * Bl, loss, d_il, d_tl, d_ia, d_ta, dls, scratch)
+        dI[sl] += d_il
+        dT[sl] += d_tl
+        dI += d_ia
+        dT += d_ta
+    check(loss, total.detach().reshape(1), "clip loss", bf16_out=False, scale=1e-5)
+    check(dI, Ir.grad, "clip dI", bf16_out=False, scale=2e-5)
+    check(dT, Tr.grad, "clip dT", bf16_out=False, scale=2e-5)
+    check(dls, lsr.grad, "clip d logit_scale", bf16_out=False, scale=2e-5)

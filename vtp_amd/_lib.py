@@ -34,6 +34,13 @@ SIGNATURES = {
     "vtp_gemm_splits": [_I, _I],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],
+    "vtp_embed_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_embed_tokens_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_gather_rows": [_P, _P, _P, _I, _I, _I, _P],
+    "vtp_scatter_rows": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_l2norm_fwd": [_P, _P, _P, _I, _I, _F, _P],
+    "vtp_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "vtp_clip_loss": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 
 _lib = None

@@ -239,11 +239,12 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
     column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
     dimension; slices write private fp32 slabs (plain stores) that one reduce kernel folds into the flat gradient."""
-    N = L.N if N is None else N
-    K = L.K if K is None else K
-    gw = L.gw if gw is None else gw
-    gb = L.gb if gb is None else gb
-    wT = L.wT if wT is None else wT
+    if L is not None:
+        N = L.N if N is None else N
+        K = L.K if K is None else K
+        gw = L.gw if gw is None else gw
+        gb = L.gb if gb is None else gb
+        wT = L.wT if wT is None else wT
     Mp = pad8(M)
     dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
     xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
@@ -282,26 +283,49 @@ class BlockW:
     pass
 
 
+# parameter names per block style (reference module trees: block.py:159-187 SelfAttentionBlock, block.py:382-399
+# ResidualAttentionBlock + nn.MultiheadAttention)
+_NAMES = {
+    "vit": dict(n1="norm1", n2="norm2", qkv_w="attn.qkv.weight", qkv_b="attn.qkv.bias", proj_w="attn.proj.weight",
+                proj_b="attn.proj.bias"),
+    "text": dict(n1="ln_1", n2="ln_2", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias",
+                 proj_w="attn.out_proj.weight", proj_b="attn.out_proj.bias"),
+}
+
+
 class Stack:
-    def __init__(self, store: ParamStore, prefix: str, depth: int, D: int, heads: int, H: int, norm: str):
-        self.store, self.depth, self.D, self.heads, self.H = store, depth, D, heads, H
+    """A run of pre-norm transformer blocks.  style "vit": SelfAttentionBlock (RoPE attention + SwiGLU FFN);
+    style "text": CLIP ResidualAttentionBlock (causal attention, no RoPE, LayerNorm eps 1e-5, erf-GELU MLP of width H)."""
+
+    def __init__(self, store: ParamStore, prefix: str, depth: int, D: int, heads: int, H: int, norm: str,
+                 style: str = "vit"):
+        self.store, self.depth, self.D, self.heads, self.H, self.style = store, depth, D, heads, H, style
         self.kind = ops.NORM_RMS if norm == "rmsnorm" else ops.NORM_LN
-        self.eps = 1e-5 if norm == "rmsnorm" else 1e-6  # RMSNorm default / partial(nn.LayerNorm, eps=1e-6)
+        if style == "text":
+            self.eps = 1e-5  # nn.LayerNorm default (normalization.py:25-31)
+        else:
+            self.eps = 1e-5 if norm == "rmsnorm" else 1e-6  # RMSNorm default / partial(nn.LayerNorm, eps=1e-6)
+        self.causal = style == "text"
+        nm = _NAMES[style]
         self.blocks: List[BlockW] = []
         for i in range(depth):
             b = BlockW()
             pre = f"{prefix}{i}."
-            b.n1w, b.gn1w = store.p(pre + "norm1.weight"), store.g(pre + "norm1.weight")
-            b.n2w, b.gn2w = store.p(pre + "norm2.weight"), store.g(pre + "norm2.weight")
+            b.n1w, b.gn1w = store.p(pre + nm["n1"] + ".weight"), store.g(pre + nm["n1"] + ".weight")
+            b.n2w, b.gn2w = store.p(pre + nm["n2"] + ".weight"), store.g(pre + nm["n2"] + ".weight")
             if self.kind == ops.NORM_LN:
-                b.n1b, b.gn1b = store.p(pre + "norm1.bias"), store.g(pre + "norm1.bias")
-                b.n2b, b.gn2b = store.p(pre + "norm2.bias"), store.g(pre + "norm2.bias")
+                b.n1b, b.gn1b = store.p(pre + nm["n1"] + ".bias"), store.g(pre + nm["n1"] + ".bias")
+                b.n2b, b.gn2b = store.p(pre + nm["n2"] + ".bias"), store.g(pre + nm["n2"] + ".bias")
             else:
                 b.n1b = b.gn1b = b.n2b = b.gn2b = None
-            b.qkv = store.lin(pre + "attn.qkv.weight", pre + "attn.qkv.bias", 3 * D, D)
-            b.proj = store.lin(pre + "attn.proj.weight", pre + "attn.proj.bias", D, D)
-            b.w12 = store.swiglu(pre + "mlp.", H, D)
-            b.w3 = store.lin(pre + "mlp.w3.weight", pre + "mlp.w3.bias", D, H)
+            b.qkv = store.lin(pre + nm["qkv_w"], pre + nm["qkv_b"], 3 * D, D)
+            b.proj = store.lin(pre + nm["proj_w"], pre + nm["proj_b"], D, D)
+            if style == "vit":
+                b.w12 = store.swiglu(pre + "mlp.", H, D)
+                b.w3 = store.lin(pre + "mlp.w3.weight", pre + "mlp.w3.bias", D, H)
+            else:
+                b.fc = store.lin(pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", H, D)
+                b.w3 = store.lin(pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", D, H)
             b.ls1 = store.p(pre + "ls1.gamma") if store.has(pre + "ls1.gamma") else None
             b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
             self.blocks.append(b)
@@ -311,6 +335,7 @@ class Stack:
         D, H, heads = self.D, self.H, self.heads
         M = B * N
         scale = 1.0 / math.sqrt(64.0)
+        vit = self.style == "vit"
         for i, b in enumerate(self.blocks):
             t = f"{i}." if train else ""
             xn1 = ws.get(t + "xn1", (M, D), BF)
@@ -321,7 +346,7 @@ class Stack:
             xmid = ws.get(t + "xmid", (M, D), F32)
             xn2 = ws.get(t + "xn2", (M, D), BF)
             st2 = ws.get(t + "st2", (M, 2), F32)
-            x12 = ws.get(t + "x12", (M, 2 * H), BF) if train else None
+            pre = ws.get(t + "x12", (M, 2 * H if vit else H), BF) if train else None  # FFN pre-activations
             hid = ws.get(t + "hid", (M, H), BF)
             xout = ws.get((f"{i}.xout" if train else f"xout{i & 1}"), (M, D), F32)
             b.x_in = x if train else None  # block input (previous block's xout buffer) is kept for norm1 backward
@@ -330,25 +355,29 @@ class Stack:
             ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
             if rope is not None:
                 ops.rope_qk(qkv, rope[0], rope[1], B, N, heads, prefix_tokens)
-            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, N, heads, N * 3 * D, 3 * D, N * D, D, scale)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, N, heads, N * 3 * D, 3 * D, N * D, D, scale, self.causal)
             ops.gemm_nt(o, b.proj.w, xmid, M=M, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, resid=x, epi=EPI_F32)
             ops.norm_fwd(xmid, b.n2w, b.n2b, xn2, st2, M, D, self.eps, self.kind)
-            ops.gemm_nt(xn2, b.w12.w12, hid, M=M, N=2 * H, K=D, c2=x12, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            if vit:
+                ops.gemm_nt(xn2, b.w12.w12, hid, M=M, N=2 * H, K=D, c2=pre, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            else:
+                ops.gemm_nt(xn2, b.fc.w, hid, M=M, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias, epi=EPI_GELU)
             ops.gemm_nt(hid, b.w3.w, xout, M=M, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, resid=xmid, epi=EPI_F32)
             if train:
-                b.saved = (xn1, st1, qkv, o, lse, xmid, xn2, st2, x12, hid)
+                b.saved = (xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid)
             x = xout
         return x
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
     def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int):
-        """Generator: yields the block index i each time all parameter gradients of block i have been enqueued (a
+        """Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
         gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input."""
         D, H, heads = self.D, self.H, self.heads
         M = B * N
         scale = 1.0 / math.sqrt(64.0)
+        vit = self.style == "vit"
         dh = ws.get("b.dh", (M, H), BF)
-        dx12 = ws.get("b.dx12", (M, 2 * H), BF)
+        dpre = ws.get("b.dx12", (M, 2 * H if vit else H), BF)
         dxn = ws.get("b.dxn", (M, D), BF)
         d_o = ws.get("b.do", (M, D), BF)
         dqkv = ws.get("b.dqkv", (M, 3 * D), BF)
@@ -358,19 +387,23 @@ class Stack:
         for i in range(self.depth - 1, -1, -1):
             b = self.blocks[i]
             assert b.ls1 is None and b.ls2 is None, "LayerScale backward is not implemented"
-            xn1, st1, qkv, o, lse, xmid, xn2, st2, x12, hid = b.saved
+            xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid = b.saved
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
-            # ---- FFN: x_out = x_mid + w3(silu(w1 xn2) * (w2 xn2))
+            # ---- FFN: x_out = x_mid + w3(act(...))
             linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh)
-            ops.swiglu_bwd(dh, x12, dx12, M, H)
-            linear_bwd(ws, "w12", None, dx12, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
-                       swiglu_h=H)
+            if vit:
+                ops.swiglu_bwd(dh, pre, dpre, M, H)
+                linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
+                           swiglu_h=H)
+            else:
+                ops.gelu_bwd(dh, pre, dpre, M * H)
+                linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn)
             ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind)
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
             linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o)
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, d_o, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], B, N, heads,
-                         N * 3 * D, 3 * D, N * D, D, scale)
+                         N * 3 * D, 3 * D, N * D, D, scale, self.causal)
             if rope is not None:
                 ops.rope_qk(dqkv, rope[0], rope[1], B, N, heads, prefix_tokens, inverse=True)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
@@ -462,6 +495,12 @@ class TrunkEngine:
         ops.gemm_nt(xnf, self.bott.w, lat, M=B * hw, N=self.bott_dim, K=self.D, epi=EPI_F32 if out_f32 else EPI_BF16,
                     a_remap=(hw, 1))
         return lat
+
+    def d_xnf_buffer(self) -> torch.Tensor:
+        """bf16 [B*N, D] gradient w.r.t. the final-norm tokens of the last forward.  Patch rows are written by
+        backward() (bottleneck dgrad); cls rows are zero unless a cls-path head (CLIP) writes them before backward()."""
+        ws, B, h, w = self._ctx[:4]
+        return ws.get("b.d_xnf", (B * (h * w + 1), self.D), BF, zero=True)
 
     def backward(self, d_lat: Optional[torch.Tensor]):
         """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g.

@@ -203,9 +203,13 @@ class VTPModel(nn.Module):
             self._trunk = TrunkEngine(st, self.config, self.trunk.rope_embed.periods)
             self._decoder = DecoderEngine(st, self.config, self.pixel_decoder.rope_embed.periods) \
                 if self.pixel_decoder is not None else None
+            self._text = self._clip = None
             if self.visual_proj is not None:
+                from .clip_engine import ClipHead, TextEngine
                 self._vproj = st.lin("visual_proj.weight", None, self.visual_proj.weight.shape[0],
                                      self.visual_proj.weight.shape[1])
+                self._text = TextEngine(st, self.config)
+                self._clip = ClipHead(st, self._vproj, self.config.vision_embed_dim, self.config.text_embed_dim)
             st.finalize()
             self._store = st
             self._pver = self._param_version()
@@ -307,14 +311,32 @@ class VTPModel(nn.Module):
         N = (H // 16) * (W // 16) + 1
         xnf = self._trunk.forward(img, train=False)  # [B*N, D] bf16; cls rows are b*N
         D = c.vision_embed_dim
-        f = torch.empty(B, self._vproj.N, dtype=torch.float32, device=img.device)
-        ops.gemm_nt(xnf, self._vproj.w, f, M=B, N=self._vproj.N, K=D, lda=N * D, epi=ops.EPI_F32)
-        return torch.nn.functional.normalize(f, dim=-1) if normalize else f
+        f = self._clip.image_features(xnf, B, N)
+        if normalize:
+            f, _ = self._clip.normalize(f, "img")
+        return f.clone()
 
+    @torch.no_grad()
     def get_clip_text_feature(self, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """modeling_vtp.py:278-310."""
         if not self.config.train_clip:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
-        raise NotImplementedError("text tower kernels land with the contrastive path (DESIGN.md 'next')")
+        self._fresh()
+        if text.ndim != 2 or text.shape[1] != self.config.text_context_length:
+            raise ValueError(f"text must be [B, {self.config.text_context_length}] token ids, got {tuple(text.shape)}")
+        ids = text.detach().to(dtype=torch.int64).contiguous()
+        f = self._text.forward(ids, train=False)
+        if normalize:
+            f, _ = self._clip.normalize(f, "txt")
+        return f.clone()
+
+    @torch.no_grad()
+    def get_clip_logits(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """modeling_vtp.py:312-333 (the [B_img, B_txt] logits GEMM is host-level glue on two small normalised matrices)."""
+        i = self.get_clip_image_feature(image, normalize=True)
+        t = self.get_clip_text_feature(text, normalize=True)
+        logits = self.logit_scale.exp() * i @ t.T
+        return logits, logits.T
 
     def forward(self, image=None, text=None, forward_type: str = "clip"):
         """modeling_vtp.py:399-472 (inference semantics)."""

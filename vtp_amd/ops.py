@@ -130,3 +130,34 @@ def reduce_slabs(slabs, stride, S, dst, n, accumulate=True):
 
 def ema(t, s, n, momentum):
     _lib.check(_lib_().vtp_ema(_p(t), _p(s), n, momentum, _s()), "vtp_ema")
+
+
+def embed_tokens(ids, table, pos, x, eot, B, T, D):
+    _lib.check(_lib_().vtp_embed_tokens(_p(ids), _p(table), _p(pos), _p(x), _p(eot), B, T, D, _s()), "vtp_embed_tokens")
+
+
+def embed_tokens_bwd(ids, dx, d_table, d_pos, B, T, D):
+    _lib.check(_lib_().vtp_embed_tokens_bwd(_p(ids), _p(dx), _p(d_table), _p(d_pos), B, T, D, _s()), "vtp_embed_tokens_bwd")
+
+
+def gather_rows(x, idx, out, B, T, D):
+    _lib.check(_lib_().vtp_gather_rows(_p(x), _p(idx), _p(out), B, T, D, _s()), "vtp_gather_rows")
+
+
+def scatter_rows(dy, idx, dx, dxb, B, T, D):
+    _lib.check(_lib_().vtp_scatter_rows(_p(dy), _p(idx), _p(dx), _p(dxb), B, T, D, _s()), "vtp_scatter_rows")
+
+
+def l2norm_fwd(x, y, inv, B, D, eps=1e-12):
+    _lib.check(_lib_().vtp_l2norm_fwd(_p(x), _p(y), _p(inv), B, D, eps, _s()), "vtp_l2norm_fwd")
+
+
+def l2norm_bwd(dy, y, inv, dx, B, D):
+    _lib.check(_lib_().vtp_l2norm_bwd(_p(dy), _p(y), _p(inv), _p(dx), B, D, _s()), "vtp_l2norm_bwd")
+
+
+def clip_loss(img_l, txt_l, img_all, txt_all, logit_scale, Bl, Bg, D, label_offset, loss_sum, d_img_l, d_txt_l, d_img_all,
+              d_txt_all, d_logit_scale, scratch):
+    _lib.check(_lib_().vtp_clip_loss(_p(img_l), _p(txt_l), _p(img_all), _p(txt_all), _p(logit_scale), Bl, Bg, D, label_offset,
+                                     _p(loss_sum), _p(d_img_l), _p(d_txt_l), _p(d_img_all), _p(d_txt_all), _p(d_logit_scale),
+                                     _p(scratch), _s()), "vtp_clip_loss")

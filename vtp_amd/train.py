@@ -8,18 +8,27 @@ loss, optimizer or DDP wrapper.  This module is that missing d
   * gradient all-reduce = a few large contiguous RCCL buckets launched *during* backward (the c10d NCCL/RCCL backend
     runs them on its own HIP stream; they overlap the remaining backward kernels) and waited on before the optimizer;
     xGMI is point-to-point, so few large messages beat many small ones;
+  * the contrastive head exchanges L2-normalised image/text features with one all-gather each and returns the
+    cross-rank feature gradients with one reduce-scatter each (OpenCLIP local_loss + gather_with_grad semantics);
+  * the whole step is captured once as a short chain of hipGraph segments (collectives stay between segments) and
+    replayed; hyper-parameters live in device memory so the replay sees per-step values;
   * one fused AdamW launch per contiguous parameter range + one batched bf16-weight refresh launch.
 
-Loss heads are OUR spec (parity unpinned by the reference): rec = mean |decode(encode(x)) - x| (L1).
+Objectives (OUR spec -- the reference defines no loss; parity unpinned):
+  rec  = mean |decode(encode(x)) - x|                       (L1)
+  clip = 0.5 * (CE(s I T^T) + CE(s T I^T)), s = exp(logit_scale), computed on the SAME trunk forward as `rec`
+         (drop rates are 0 and the input is the same image, so trunk(image) is identical for both objectives and the
+         shared forward/backward is mathematically the sum of the two separate passes).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+import math
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from . import ops
-from .engine import BF, F32
+from .engine import BF, F32, OVERLAP
 
 
 class GradBucketer:
@@ -33,6 +42,7 @@ class GradBucketer:
         self.flat_g = flat_g
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.works = []
         self.reduced_elems = 0
 
@@ -70,26 +80,35 @@ def param_ranges(offsets, prefixes: Sequence[str]) -> List[Tuple[int, int]]:
     return merge_ranges(r)
 
 
+CLIP_PREFIXES = ("visual_proj.", "text_transformer.", "token_embedding.", "positional_embedding", "ln_final.",
+                 "text_projection", "logit_scale")
+
+
 class VTPTrainer:
-    """Reconstruction-path trainer (BASELINE config 2 and the `rec` third of config 3)."""
+    """Trainer for the reconstruction (+ optional contrastive) objectives: BASELINE config 2 and the rec + clip parts of
+    config 3.  `step(images)` = rec only; `step(images, text)` = rec + clip."""
 
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
-                 group=None, bucket_blocks: int = 3, use_graphs: bool = False):
+                 group=None, bucket_blocks: int = 3, use_graphs: bool = False, clip_weight: float = 1.0,
+                 rec_weight: float = 1.0):
         self.model = model
         self.store = model._engine()
         self.trunk, self.decoder = model._trunk, model._decoder
+        self.text, self.clip = model._text, model._clip
         if self.decoder is None:
             raise RuntimeError("VTPTrainer needs train_reconstruction=True")
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.clip_weight, self.rec_weight = clip_weight, rec_weight
         st = self.store
-        self.ranges = param_ranges(st.offsets, ("trunk.", "pixel_decoder."))
-        # visual_proj sits between trunk.* and pixel_decoder.* in registration order; it takes no gradient on the rec path
+        self.ranges_rec = param_ranges(st.offsets, ("trunk.", "pixel_decoder."))
+        self.ranges_all = param_ranges(st.offsets, ("trunk.", "pixel_decoder.") + CLIP_PREFIXES)
         self.m = torch.zeros_like(st.flat_p)
         self.v = torch.zeros_like(st.flat_p)
         self.step_no = 0
-        self.loss_sum = torch.zeros(1, dtype=F32, device=st.device)
+        self.loss_sum = torch.zeros(1, dtype=F32, device=st.device)       # L1 numerator
+        self.clip_loss_sum = torch.zeros(1, dtype=F32, device=st.device)  # contrastive loss (already a mean)
         self.bucketer = GradBucketer(st.flat_g, group)
-        self.world = self.bucketer.world
+        self.world, self.rank, self.group = self.bucketer.world, self.bucketer.rank, group
         self.bucket_blocks = bucket_blocks
         self._bucket_plan = self._plan_buckets()
         # hyper-parameters live in device memory so that captured hipGraphs replay with per-step values
@@ -98,20 +117,26 @@ class VTPTrainer:
         self.use_graphs = use_graphs
         self._graphs = {}
 
-    # gradient buckets in backward-completion order: decoder tail, decoder blocks (high->low), trunk blocks, trunk head
+    # gradient buckets in backward-completion order
     def _plan_buckets(self):
         off = self.store.offsets
 
-        def rng(prefix):
-            return param_ranges(off, (prefix,))
+        def rng(*prefixes):
+            return param_ranges(off, prefixes)
 
-        plan = {"dec_tail": rng("pixel_decoder.norm.") + rng("pixel_decoder.proj_out."),
+        plan = {"dec_tail": rng("pixel_decoder.norm.", "pixel_decoder.proj_out."),
                 "dec_head": rng("pixel_decoder.proj_in."),
-                "trunk_tail": rng("trunk.norm.") + rng("trunk.feature_bottleneck."),
-                "trunk_head": rng("trunk.cls_token") + rng("trunk.mask_token") + rng("trunk.patch_embed.")}
-        for key, tower, depth in (("dec", "pixel_decoder", self.decoder.depth), ("trunk", "trunk", self.trunk.depth)):
+                "trunk_tail": rng("trunk.norm.", "trunk.feature_bottleneck."),
+                "trunk_head": rng("trunk.cls_token", "trunk.mask_token", "trunk.patch_embed."),
+                "text_tail": rng("ln_final.", "text_projection"),
+                "text_head": rng("token_embedding.", "positional_embedding"),
+                "clip_head": rng("visual_proj.", "logit_scale")}
+        towers = [("dec", "pixel_decoder.blocks.", self.decoder.depth), ("trunk", "trunk.blocks.", self.trunk.depth)]
+        if self.text is not None:
+            towers.append(("text", "text_transformer.resblocks.", self.text.depth))
+        for key, prefix, depth in towers:
             for i in range(depth):
-                plan[f"{key}.{i}"] = rng(f"{tower}.blocks.{i}.")
+                plan[f"{key}.{i}"] = rng(f"{prefix}{i}.")
         return plan
 
     def _reduce(self, keys: Sequence[str]):
@@ -122,9 +147,10 @@ class VTPTrainer:
             self.bucketer.reduce_range(lo, hi)
 
     # ------------------------------------------------------------------------------------------------------------
-    # The step is written ONCE as a generator.  Every `yield keys` is a point where the gradients of the parameter
-    # groups `keys` are complete: the eager driver launches their RCCL all-reduce there; the graph driver ends a
-    # hipGraph segment there (collectives stay outside the graphs, between segment launches).
+    # The step is written ONCE as a generator.  It yields either
+    #   * a list of bucket keys: the gradients of those parameter groups are complete -> the driver launches their RCCL
+    #     all-reduce (eager) / ends a hipGraph segment there and launches the all-reduce between segments; or
+    #   * a callable: a collective that must run between segments (feature all-gather / reduce-scatter).
     # ------------------------------------------------------------------------------------------------------------
     def _tower_backward(self, tower: str, gen, depth: int):
         nb = self.bucket_blocks
@@ -141,24 +167,79 @@ class VTPTrainer:
             result = stop.value
         return result
 
-    def _step_gen(self, images: torch.Tensor):
+    def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor]):
         st = self.store
+        dist = self.bucketer.dist
         B, _, H, W = images.shape
         h, w = H // 16, W // 16
+        N = h * w + 1
         st.zero_grad()
         self.loss_sum.zero_()
-        self.trunk.forward(images, train=True)
+        self.clip_loss_sum.zero_()
+        xnf = self.trunk.forward(images, train=True)
         lat = self.trunk.latents()
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
-        ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, 1.0 / (B * 3 * H * W))
+        ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
+        if text is not None:
+            d_xnf = self.trunk.d_xnf_buffer()
+            cw = self.clip.ws
+            Dt = self.clip.Dt
+            f_img = self.clip.image_features(xnf, B, N)
+            img_n, inv_i = self.clip.normalize(f_img, "img")
+            f_txt = self.text.forward(text, train=True)
+            txt_n, inv_t = self.clip.normalize(f_txt, "txt")
+            Bg = B * self.world
+            if self.world > 1:
+                img_all = cw.get("img_all", (Bg, Dt), F32)
+                txt_all = cw.get("txt_all", (Bg, Dt), F32)
+
+                def gather():
+                    dist.all_gather_into_tensor(img_all, img_n, group=self.group)
+                    dist.all_gather_into_tensor(txt_all, txt_n, group=self.group)
+                yield gather
+            else:
+                img_all, txt_all = img_n, txt_n
+            d_img_l = cw.get("d_img_l", (B, Dt), F32)
+            d_txt_l = cw.get("d_txt_l", (B, Dt), F32)
+            d_img_all = cw.get("d_img_all", (Bg, Dt), F32)
+            d_txt_all = cw.get("d_txt_all", (Bg, Dt), F32)
+            scratch = cw.get("logits", (2 * B * Bg,), F32)
+            ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
+                          d_img_l, d_txt_l, d_img_all, d_txt_all, st.g("logit_scale"), scratch)
+            if self.world > 1:
+                rs_i = cw.get("rs_i", (B, Dt), F32)
+                rs_t = cw.get("rs_t", (B, Dt), F32)
+
+                def scatter():
+                    dist.reduce_scatter_tensor(rs_i, d_img_all, group=self.group)
+                    dist.reduce_scatter_tensor(rs_t, d_txt_all, group=self.group)
+                yield scatter
+            else:
+                rs_i, rs_t = d_img_all, d_txt_all
+            # total feature gradient = local-loss term + the terms every rank's loss contributes to these rows
+            ops.reduce_slabs(rs_i, B * Dt, 1, d_img_l, B * Dt, accumulate=True)
+            ops.reduce_slabs(rs_t, B * Dt, 1, d_txt_l, B * Dt, accumulate=True)
+            if self.clip_weight != 1.0:
+                d_img_l.mul_(self.clip_weight)
+                d_txt_l.mul_(self.clip_weight)
+                st.g("logit_scale").mul_(self.clip_weight)
+            d_f_txt = self.clip.normalize_bwd(d_txt_l, txt_n, inv_t, "txt")
+            yield from self._tower_backward("text", self.text.backward(d_f_txt), self.text.depth)
+            yield ["text_head"]
+            d_f_img = self.clip.normalize_bwd(d_img_l, img_n, inv_i, "img")
+            self.clip.image_backward(d_f_img, xnf, d_xnf, B, N)  # writes the cls rows of d_xnf
+            OVERLAP.join()
+            yield ["clip_head"]
         d_lat = yield from self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
         yield ["dec_head"]
         yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
-        yield ["trunk_head"]
+        yield ["trunk_head", "FINAL"]
         # ---- optimizer (after every bucket has been reduced)
-        for lo, hi in self.ranges:
+        for lo, hi in (self.ranges_all if text is not None else self.ranges_rec):
             ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
+        if text is not None:
+            st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         st.prep()
 
     def _set_hyper(self):
@@ -169,45 +250,52 @@ class VTPTrainer:
         self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
         self.hyper.copy_(self._hyper_host, non_blocking=True)
 
-    def step_rec(self, images: torch.Tensor) -> torch.Tensor:
-        """One optimizer step on the L1 reconstruction loss.  images: f32 [B,3,H,W] on the device.
-        Returns the (local) loss as a device scalar tensor (no host sync)."""
+    def _handle(self, ev):
+        if callable(ev):
+            ev()
+            return
+        final = "FINAL" in ev
+        self._reduce([k for k in ev if k != "FINAL"])
+        if final:
+            self.bucketer.wait()  # the generator's next (last) leg is the optimizer
+
+    def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None):
+        """One optimizer step.  images: f32 [B,3,H,W]; text: int64 [B, context_length] or None (rec only).
+        Returns (rec_loss, clip_loss) as device scalar tensors (local to this rank; no host sync)."""
+        if text is not None and self.text is None:
+            raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
         B, _, H, W = images.shape
         self._set_hyper()
         if self.use_graphs:
-            self._step_graphs(images)
+            self._step_graphs(images, text)
         else:
-            gen = self._step_gen(images)
-            pending_wait = False
-            for keys in gen:
-                if keys == ["trunk_head"]:
-                    self._reduce(keys)
-                    self.bucketer.wait()  # the generator's next (last) leg is the optimizer
-                    pending_wait = True
-                else:
-                    self._reduce(keys)
-            assert pending_wait
+            for ev in self._step_gen(images, text):
+                self._handle(ev)
         self.model._pver = self.model._param_version()
-        return self.loss_sum / float(B * 3 * H * W)
+        return self.loss_sum / float(B * 3 * H * W), self.clip_loss_sum
+
+    def step_rec(self, images: torch.Tensor) -> torch.Tensor:
+        return self.step(images, None)[0]
 
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
-    def _step_graphs(self, images: torch.Tensor):
-        key = tuple(images.shape)
+    def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor]):
+        key = (tuple(images.shape), None if text is None else tuple(text.shape))
         plan = self._graphs.get(key)
         if plan is None:
-            # warm-up in eager mode on a side stream (allocates every workspace buffer, sets kernel attributes)
-            static_img = torch.empty_like(images)
-            static_img.copy_(images)
-            snap = (self.store.flat_p.clone(), self.m.clone(), self.v.clone())
+            st = self.store
+            static_img = images.clone()
+            static_txt = None if text is None else text.clone()
+            snap = (st.flat_p.clone(), self.m.clone(), self.v.clone())
+            # warm-up in eager mode on a side stream (allocates every workspace buffer, sets kernel attributes); the
+            # collectives run for real so that all ranks stay in lock-step
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for _ in self._step_gen(static_img):
-                    pass
+                for ev in self._step_gen(static_img, static_txt):
+                    self._handle(ev)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            # the warm-up performed a real (local, un-reduced) optimizer step: roll parameters and moments back
-            st = self.store
+            # the warm-up performed a real optimizer step: roll parameters and moments back
             st.flat_p.copy_(snap[0])
             self.m.copy_(snap[1])
             self.v.copy_(snap[2])
@@ -215,24 +303,24 @@ class VTPTrainer:
             del snap
             segs = []
             pool = torch.cuda.graph_pool_handle()
-            gen = self._step_gen(static_img)
+            gen = self._step_gen(static_img, static_txt)
             done = False
             while not done:
                 g = torch.cuda.CUDAGraph()
-                keys = None
+                ev = None
                 with torch.cuda.graph(g, pool=pool):
                     try:
-                        keys = next(gen)
+                        ev = next(gen)
                     except StopIteration:
                         done = True
-                segs.append((g, keys))
-            plan = (static_img, segs)
+                segs.append((g, ev))
+            plan = (static_img, static_txt, segs)
             self._graphs[key] = plan
-        static_img, segs = plan
+        static_img, static_txt, segs = plan
         static_img.copy_(images)
-        for g, keys in segs:
+        if text is not None:
+            static_txt.copy_(text)
+        for g, ev in segs:
             g.replay()
-            if keys is not None:
-                self._reduce(keys)
-                if keys == ["trunk_head"]:
-                    self.bucketer.wait()
+            if ev is not None:
+                self._handle(ev)
