@@ -46,6 +46,12 @@ const char* vtp_last_error(void);
  */
 enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4, VTP_EPI_F32_SLAB = 5 };
 int vtp_gemm_splits(int K, int splits);
+/* C[M,N] f32 = A[K,M]^T * B[K,N]: A, B bf16 row-major with the reduction dimension (tokens) as ROWS -- the weight-gradient
+ * GEMM dW = dY^T X of every linear, read straight from the activation layouts (fragments are formed with the gfx950 LDS
+ * transpose read; no transposed copies).  epilogue VTP_EPI_F32 (C = resid + acc, pass resid = C to accumulate) or
+ * VTP_EPI_F32_SLAB (split-K slabs, see above).  a_/b_ remaps act on the token rows of A / B, c_ on the rows of C. */
+int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid, int M, int N,
+                int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre, int splits, void* stream);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
@@ -96,6 +102,8 @@ int vtp_assemble_tokens(float* x, const float* cls, const float* mask_token, con
  * in_grp/in_pre: input row remap row(r) = r + (r / in_grp + 1) * in_pre (in_grp = 0: none), as in vtp_gemm_nt. */
 int vtp_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, float* colsum, int colsum_swiglu_h, int in_grp,
                        int in_pre, int R, int C, void* stream);
+/* out[c'] += sum_r in[r, c] for a bf16 [R, C] matrix (bias gradient); same column / row remaps as vtp_transpose_bf16. */
+int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_swiglu_h, int in_grp, int in_pre, int R, int C, void* stream);
 /* out[d] += sum_b in[b*stride + d], f32 (gradient of the broadcast cls token, vision_transformer.py:210-217). */
 int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream);
 

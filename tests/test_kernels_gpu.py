@@ -485,3 +485,52 @@ def test_clip_loss_with_emulated_ranks(world, Bl, D):
     check(dI, Ir.grad, "clip dI", bf16_out=False, scale=2e-5)
     check(dT, Tr.grad, "clip dT", bf16_out=False, scale=2e-5)
     check(dls, lsr.grad, "clip d logit_scale", bf16_out=False, scale=2e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------- TN GEMM (wgrad)
+@pytest.mark.parametrize("Mo,No,K,splits", [(128, 128, 64, 1), (768, 768, 8224, 11), (2304, 768, 8224, 4), (344, 128, 515, 1),
+                                            (64, 768, 8192, 3), (128, 688, 1000, 2)])
+def test_gemm_tn_matches_reference(Mo, No, K, splits):
+    """C[Mo,No] = A[K,Mo]^T B[K,No] (weight gradient from untransposed activations) incl. token/column tails."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(Mo + No + K)
+    A = bf(torch.randn(K, Mo, device=DEV, generator=g) + torch.linspace(-1, 1, Mo, device=DEV)[None, :])
+    Bm = bf(torch.randn(K, No, device=DEV, generator=g))
+    ref = A.float().T @ Bm.float()
+    S = o.gemm_splits(K, splits)
+    if S == 1:
+        C = torch.ones(Mo, No, device=DEV)
+        o.gemm_tn(A, Bm, C, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, resid=C, epi=o.EPI_F32)
+        check(C, 1 + ref, f"gemm_tn {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)
+    else:
+        slab = torch.full((S * Mo * No,), float("nan"), device=DEV)
+        o.gemm_tn(A, Bm, slab, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, ldc2=Mo * No // 4, epi=o.EPI_F32_SLAB, splits=S)
+        C = torch.ones(Mo, No, device=DEV)
+        o.reduce_slabs(slab, Mo * No, S, C, Mo * No, accumulate=True)
+        check(C, 1 + ref, f"gemm_tn split {Mo}x{No}x{K} S={S}", bf16_out=False, scale=2e-5)
+
+
+def test_gemm_tn_remaps_and_colsum():
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    B, hw, D, H = 3, 36, 128, 176
+    full = bf(torch.randn(B * (hw + 1), D, device=DEV, generator=g))      # token stream with cls rows
+    dy = bf(torch.randn(B * hw, 2 * H, device=DEV, generator=g))          # compact, SwiGLU-interleaved columns
+    C = torch.zeros(2 * H, D, device=DEV)
+    o.gemm_tn(dy, full, C, M=2 * H, N=D, K=B * hw, lda=2 * H, ldb=D, ldc=D, resid=C, epi=o.EPI_F32, b_remap=(hw, 1),
+              c_remap=(-1, H))
+    patches = full.view(B, hw + 1, D)[:, 1:].reshape(-1, D).float()
+    ref_i = dy.float().T @ patches                                        # rows in interleaved order
+    gi = torch.arange(2 * H, device=DEV)
+    dst = (gi // 16) * 8 + (gi % 8) + ((gi % 16) >= 8) * H
+    ref = torch.zeros_like(ref_i)
+    ref[dst] = ref_i
+    check(C, ref, "gemm_tn b_remap + swiglu c_remap", bf16_out=False, scale=2e-5)
+    cs = torch.ones(2 * H, device=DEV)
+    o.colsum_bf16(dy, 2 * H, cs, B * hw, 2 * H, swiglu_h=H)
+    refc = torch.zeros(2 * H, device=DEV)
+    refc[dst] = dy.float().sum(0)
+    check(cs, 1 + refc, "colsum swiglu", bf16_out=False, scale=1e-5)
+    cs2 = torch.zeros(D, device=DEV)
+    o.colsum_bf16(full, D, cs2, B * hw, D, in_remap=(hw, 1))
+    check(cs2, patches.sum(0), "colsum in_remap", bf16_out=False, scale=1e-5)

@@ -184,6 +184,39 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
   }
 }
 
+// out[c'] += sum_r in[r, c]  (bias gradients); block = 64 columns x 256 rows
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ in, int ld, float* __restrict__ out,
+                                                          int R, int C, int csum_H, int in_grp, int in_pre) {
+  __shared__ float part[32][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 256;
+  const int tid = threadIdx.x;
+  const int cc = (tid & 7) * 8, rr = tid >> 3;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 + cc < C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + rr + 32 * k;
+      if (r < R) {
+        const int rin = in_grp > 0 ? r + (r / in_grp + 1) * in_pre : r;
+        bf16x8 v = *(const bf16x8*)(in + (size_t)rin * ld + c0 + cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[rr][cc + e] = acc[e];
+  __syncthreads();
+  if (tid < 64 && c0 + tid < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += part[k][tid];
+    const int c = c0 + tid;
+    const int dst = csum_H > 0 ? ((c >> 4) << 3) + (c & 7) + ((c & 8) ? csum_H : 0) : c;
+    unsafeAtomicAdd(out + dst, s);
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, long n) {
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L)
@@ -404,6 +437,14 @@ extern "C" int vtp_transpose_bf16(const void* in, int ld_in, void* out, int ld_o
   dim3 grid(cdiv(C, 64), cdiv(ld_out, 64));
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld_in, (bf16*)out, ld_out, colsum, R, C, colsum_swiglu_h, in_grp, in_pre);
   return check_launch("transpose_bf16");
+}
+
+extern "C" int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_swiglu_h, int in_grp, int in_pre, int R, int C,
+                               void* stream) {
+  VTP_REQUIRE(in && out && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "vtp_colsum_bf16: bad argument (C, ld %% 8 == 0)");
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld,
+                     out, R, C, colsum_swiglu_h, in_grp, in_pre);
+  return check_launch("colsum_bf16");
 }
 
 extern "C" int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream) {

@@ -33,6 +33,7 @@ struct GemmArgs {
   int lda, ldb, ldc, ldc2;
   int a_grp, a_pre;  // A row remap: row(m) = m + (m / a_grp + 1) * a_pre   (a_grp == 0: identity)
   int c_grp, c_pre;  // C row remap (same formula; c_grp < 0: SwiGLU de-interleave)
+  int b_grp, b_pre;  // TRANS mode only: token-row remap of the B operand
   int k_split;       // K elements per blockIdx.z slice (multiple of 64)
   int xcd_swizzle;
   float alpha;
@@ -51,7 +52,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+// TRANS = false: A [M, K], B [N, K] (both K-contiguous).
+// TRANS = true : A [K, M], B [K, N] row-major (K = reduction = tokens): C = A^T B without materialising the transposes
+//                (weight gradients dW = dY^T X straight from the activation layouts).  The LDS image of a tile is then
+//                [64 k][BM or BN cols] as in global memory (slot index XOR 4*(k&3)), and MFMA fragments are formed with
+//                ds_read_b64_tr_b16: 16 lanes fetch a 4(k) x 16(col) block and each lane receives one column.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int BK = 64;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -89,25 +95,47 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   const int slot = lane & 7;   // 16-B slot inside the 128-B row
   const char* a_src[PA];
   const char* b_src[PB];
-  int a_kc[PA], b_kc[PB];  // this lane's source k offset (elements) inside the k-tile
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int row = (wave * PA + i) * 8 + prow;
-    const int c = slot ^ ((row >> 1) & 7);
-    int m = min(m0 + row, p.M - 1);
-    m = remap_row(m, p.a_grp, p.a_pre);
-    a_src[i] = (const char*)(p.A + (size_t)m * p.lda + kbeg + c * 8);
-    a_kc[i] = c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int row = (wave * PB + i) * 8 + prow;
-    const int c = slot ^ ((row >> 1) & 7);
-    const int n = min(n0 + row, p.N - 1);
-    b_src[i] = (const char*)(p.B + (size_t)n * p.ldb + kbeg + c * 8);
-    b_kc[i] = c * 8;
-  }
+  int a_kc[PA], b_kc[PB];  // NT: this lane's source k offset (elements) inside the k-tile | TRANS: tile row (k) of the piece
   const char* zsrc = (const char*)g_zero_block;
+  if constexpr (!TRANS) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = (wave * PA + i) * 8 + prow;
+      const int c = slot ^ ((row >> 1) & 7);
+      int m = min(m0 + row, p.M - 1);
+      m = remap_row(m, p.a_grp, p.a_pre);
+      a_src[i] = (const char*)(p.A + (size_t)m * p.lda + kbeg + c * 8);
+      a_kc[i] = c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int row = (wave * PB + i) * 8 + prow;
+      const int c = slot ^ ((row >> 1) & 7);
+      const int n = min(n0 + row, p.N - 1);
+      b_src[i] = (const char*)(p.B + (size_t)n * p.ldb + kbeg + c * 8);
+      b_kc[i] = c * 8;
+    }
+  } else {
+    // piece q of a [64 k][W cols] tile: byte q*1024 + lane*16 -> tile row r, stored slot s' ; source chunk s = s' ^ 4*(r&3)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int byte = (wave * PA + i) * 1024 + lane * 16;
+      const int r = byte / (BM * 2);
+      const int sp = (byte % (BM * 2)) >> 4;
+      const int col = m0 + ((sp ^ (4 * (r & 3))) << 3);
+      a_kc[i] = r;
+      a_src[i] = col < p.M ? (const char*)(p.A + col) : nullptr;  // column base; the token row is added per stage
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int byte = (wave * PB + i) * 1024 + lane * 16;
+      const int r = byte / (BN * 2);
+      const int sp = (byte % (BN * 2)) >> 4;
+      const int col = n0 + ((sp ^ (4 * (r & 3))) << 3);
+      b_kc[i] = r;
+      b_src[i] = col < p.N ? (const char*)(p.B + col) : nullptr;
+    }
+  }
 
   auto stage = [&](int buf, int kt) {
     char* abase = smem + buf * STAGE_BYTES;
@@ -115,14 +143,26 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
     const int krem = kend - kbeg - kt * BK;  // valid k elements left in this tile (>0)
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const char* s = (a_kc[i] < krem) ? a_src[i] + (size_t)kt * (BK * 2) : zsrc;
+      const char* s;
+      if constexpr (!TRANS) {
+        s = (a_kc[i] < krem) ? a_src[i] + (size_t)kt * (BK * 2) : zsrc;
+      } else {
+        const int t = kbeg + kt * BK + a_kc[i];
+        s = (a_kc[i] < krem && a_src[i]) ? a_src[i] + (size_t)remap_row(t, p.a_grp, p.a_pre) * p.lda * 2 : zsrc;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                        (__attribute__((address_space(3))) void*)(abase + (wave * PA + i) * 1024),
                                        16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const char* s = (b_kc[i] < krem) ? b_src[i] + (size_t)kt * (BK * 2) : zsrc;
+      const char* s;
+      if constexpr (!TRANS) {
+        s = (b_kc[i] < krem) ? b_src[i] + (size_t)kt * (BK * 2) : zsrc;
+      } else {
+        const int t = kbeg + kt * BK + b_kc[i];
+        s = (b_kc[i] < krem && b_src[i]) ? b_src[i] + (size_t)remap_row(t, p.b_grp, p.b_pre) * p.ldb * 2 : zsrc;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                        (__attribute__((address_space(3))) void*)(bbase + (wave * PB + i) * 1024),
                                        16, 0, 0);
@@ -164,14 +204,40 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
     const char* bbase = abase + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int coff = ((2 * ks + hi) ^ sw) << 4;
       bf16x8 wf[TN], xf[TM];
+      if constexpr (!TRANS) {
+        const int coff = ((2 * ks + hi) ^ sw) << 4;
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-        wf[i] = *(const bf16x8*)(bbase + (wn * WTN + i * 32) * 128 + rowoff + coff);
+        for (int i = 0; i < TN; ++i)
+          wf[i] = *(const bf16x8*)(bbase + (wn * WTN + i * 32) * 128 + rowoff + coff);
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
-        xf[j] = *(const bf16x8*)(abase + (wm * WTM + j * 32) * 128 + rowoff + coff);
+        for (int j = 0; j < TM; ++j)
+          xf[j] = *(const bf16x8*)(abase + (wm * WTM + j * 32) * 128 + rowoff + coff);
+      } else {
+        // lane (i = lane&15, g = (lane>>4)&1, hi): column c = base + 16 g + i of the block is delivered to this lane;
+        // it supplies the address of row (i>>2), 4 columns starting at 4*(i&3).  Two reads = k 8hi..8hi+3 and 8hi+4..8hi+7.
+        const int li = lane & 15, lg = (lane >> 4) & 1;
+        const int rq = li >> 2;                       // row inside the 4-row block == (row & 3) -> swizzle key
+        const int cin = lg * 16 + (li & 3) * 4;       // column offset inside the 32-column fragment block
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int col = wn * WTN + i * 32 + cin;
+          const int soff = (((col >> 3) ^ (4 * rq)) << 4) + ((col & 7) << 1);
+          const char* b0 = bbase + (ks * 16 + hi * 8 + rq) * (BN * 2) + soff;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)b0);
+          bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(b0 + 4 * (BN * 2)));
+          wf[i] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int col = wm * WTM + j * 32 + cin;
+          const int soff = (((col >> 3) ^ (4 * rq)) << 4) + ((col & 7) << 1);
+          const char* a0 = abase + (ks * 16 + hi * 8 + rq) * (BM * 2) + soff;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+          bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * (BM * 2)));
+          xf[j] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -267,18 +333,18 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS>
 static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
   constexpr int LDS = STAGES * (BM + BN) * 64 * 2;
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, TRANS>;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), LDS, s, a);
-  return check_launch("gemm_nt");
+  return check_launch(TRANS ? "gemm_tn" : "gemm_nt");
 }
 
 // tile configurations (cfg id): 0 = 128x128 4 waves 2 stages | 1 = 128x128 4w 3 stages | 2 = 256x128 8w 2 stages |
@@ -286,16 +352,25 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
 static int g_force_cfg = -1;
 static int g_xcd_swizzle = 1;
 
-template <int EPI>
+template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
-  switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 3, EPI>(a, splits, s);
-    case 2: return launch_cfg<256, 128, 4, 2, 2, EPI>(a, splits, s);
-    case 3: return launch_cfg<256, 128, 4, 2, 3, EPI>(a, splits, s);
-    case 4: return launch_cfg<256, 256, 4, 2, 2, EPI>(a, splits, s);
-    case 5: return launch_cfg<128, 128, 4, 2, 2, EPI>(a, splits, s);
-    case 6: return launch_cfg<128, 128, 2, 2, 4, EPI>(a, splits, s);
-    default: return launch_cfg<128, 128, 2, 2, 2, EPI>(a, splits, s);
+  if constexpr (TRANS) {  // weight-gradient shapes only: keep the instantiation count small
+    switch (cfg) {
+      case 2: return launch_cfg<256, 128, 4, 2, 2, EPI, true>(a, splits, s);
+      case 3: return launch_cfg<256, 128, 4, 2, 3, EPI, true>(a, splits, s);
+      case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, true>(a, splits, s);
+      default: return launch_cfg<128, 128, 2, 2, 2, EPI, true>(a, splits, s);
+    }
+  } else {
+    switch (cfg) {
+      case 1: return launch_cfg<128, 128, 2, 2, 3, EPI, false>(a, splits, s);
+      case 2: return launch_cfg<256, 128, 4, 2, 2, EPI, false>(a, splits, s);
+      case 3: return launch_cfg<256, 128, 4, 2, 3, EPI, false>(a, splits, s);
+      case 4: return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, splits, s);
+      case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, false>(a, splits, s);
+      case 6: return launch_cfg<128, 128, 2, 2, 4, EPI, false>(a, splits, s);
+      default: return launch_cfg<128, 128, 2, 2, 2, EPI, false>(a, splits, s);
+    }
   }
 }
 
@@ -341,6 +416,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = C2; a.bias = bias; a.gamma = gamma; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = alpha;
+  a.b_grp = 0; a.b_pre = 0;
   a.xcd_swizzle = g_xcd_swizzle;
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;
@@ -348,15 +424,42 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   hipStream_t s = (hipStream_t)stream;
   const int cfg = pick_cfg(M, N, K, epilogue, splits);
   switch (epilogue) {
-    case VTP_EPI_BF16: return launch_gemm<EPI_BF16>(a, 1, cfg, s);
-    case VTP_EPI_F32: return launch_gemm<EPI_F32>(a, 1, cfg, s);
+    case VTP_EPI_BF16: return launch_gemm<EPI_BF16, false>(a, 1, cfg, s);
+    case VTP_EPI_F32: return launch_gemm<EPI_F32, false>(a, 1, cfg, s);
     case VTP_EPI_SWIGLU:
       VTP_REQUIRE(N % 16 == 0 && bias, "vtp_gemm_nt: SwiGLU epilogue needs interleaved N %% 16 == 0 and a bias");
-      return launch_gemm<EPI_SWIGLU>(a, 1, cfg, s);
-    case VTP_EPI_GELU: return launch_gemm<EPI_GELU>(a, 1, cfg, s);
-    case VTP_EPI_F32_ATOMIC: return launch_gemm<EPI_F32_ATOMIC>(a, splits, cfg, s);
-    case VTP_EPI_F32_SLAB: return launch_gemm<EPI_F32_SLAB>(a, splits, cfg, s);
+      return launch_gemm<EPI_SWIGLU, false>(a, 1, cfg, s);
+    case VTP_EPI_GELU: return launch_gemm<EPI_GELU, false>(a, 1, cfg, s);
+    case VTP_EPI_F32_ATOMIC: return launch_gemm<EPI_F32_ATOMIC, false>(a, splits, cfg, s);
+    case VTP_EPI_F32_SLAB: return launch_gemm<EPI_F32_SLAB, false>(a, splits, cfg, s);
     default: VTP_REQUIRE(false, "vtp_gemm_nt: unknown epilogue %d", epilogue);
   }
   return VTP_OK;
+}
+
+// C[M,N] (f32) = A[K,M]^T * B[K,N]  (A, B bf16 row-major with the reduction dimension K = tokens as rows):
+// the weight-gradient GEMM dW = dY^T X straight from the activation layouts (no transposed copies).
+extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid,
+                           int M, int N, int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre,
+                           int splits, void* stream) {
+  VTP_REQUIRE(A && B && C, "vtp_gemm_tn: null operand");
+  VTP_REQUIRE(M > 0 && N > 0 && K > 0, "vtp_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+  VTP_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "vtp_gemm_tn: M, N, lda, ldb must be multiples of 8");
+  VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "vtp_gemm_tn: operands must be 16-B aligned");
+  VTP_REQUIRE(epilogue == VTP_EPI_F32 || epilogue == VTP_EPI_F32_SLAB, "vtp_gemm_tn: epilogue must be F32 (accumulate via resid) or F32_SLAB");
+  VTP_REQUIRE(splits >= 1 && (splits == 1 || epilogue == VTP_EPI_F32_SLAB), "vtp_gemm_tn: split-K needs the slab epilogue");
+  VTP_REQUIRE(epilogue != VTP_EPI_F32_SLAB || ldc2 > 0, "vtp_gemm_tn: slab epilogue needs ldc2 = slab stride / 4");
+  GemmArgs a;
+  a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = nullptr; a.bias = nullptr; a.gamma = nullptr; a.resid = resid;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
+  a.a_grp = a_grp; a.a_pre = a_pre; a.b_grp = b_grp; a.b_pre = b_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = 1.f;
+  a.xcd_swizzle = g_xcd_swizzle;
+  int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
+  a.k_split = ks;
+  splits = (K + ks - 1) / ks;
+  int cfg = g_force_cfg >= 0 ? g_force_cfg : ((M >= 256 && splits > 1) ? 3 : 5);
+  if (cfg != 2 && cfg != 3 && cfg != 5) cfg = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (epilogue == VTP_EPI_F32) return launch_gemm<EPI_F32, true>(a, 1, cfg, s);
+  return launch_gemm<EPI_F32_SLAB, true>(a, splits, cfg, s);
 }

@@ -224,6 +224,9 @@ class Overlap:
 
 
 OVERLAP = Overlap()
+# weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
+import os as _os
+WGRAD_TN = _os.environ.get("VTP_WGRAD", "tn") != "transpose"
 
 
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
@@ -246,12 +249,27 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         gb = L.gb if gb is None else gb
         wT = L.wT if wT is None else wT
     Mp = pad8(M)
-    dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
-    xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
     c_remap = (-1, swiglu_h) if swiglu_h else (0, 0)
     S = ops.gemm_splits(Mp, _wgrad_splits(N, K, Mp))
 
     def wgrad():
+        if WGRAD_TN:
+            # dW[N,K] = dy[M,N]^T x[M,K] straight from the activation layouts (LDS transpose reads inside the GEMM)
+            if gb is not None:
+                ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
+            kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap,
+                      c_remap=c_remap)
+            St = ops.gemm_splits(M, _wgrad_splits(N, K, M))
+            if St == 1:
+                ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)
+            else:
+                n_el = N * K
+                slab = ws.get("T.slab", (St * n_el,), F32)
+                ops.gemm_tn(dy_b, x_b, slab, ldc2=n_el // 4, epi=EPI_F32_SLAB, splits=St, **kw)
+                ops.reduce_slabs(slab, n_el, St, gw, n_el, accumulate=True)
+            return
+        dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
+        xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
         ops.transpose_bf16(dy_b, dy_b.stride(0), dyT, Mp, M, N, colsum=gb, swiglu_h=swiglu_h, in_remap=dy_remap)
         ops.transpose_bf16(x_b, x_b.stride(0), xT, Mp, M, K, in_remap=x_remap)
         if S == 1:

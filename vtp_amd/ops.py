@@ -120,6 +120,18 @@ def adamw_dev(p, g, m, v, p_bf16, n, hyper):
     _lib.check(_lib_().vtp_adamw_dev(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _s()), "vtp_adamw_dev")
 
 
+def gemm_tn(a, b, c, *, M, N, K, lda, ldb, ldc, ldc2=0, resid=None, epi=EPI_F32, a_remap=(0, 0), b_remap=(0, 0),
+            c_remap=(0, 0), splits=1):
+    """c[M,N] f32 = a[K,M]^T @ b[K,N]  (a, b bf16 row-major, K = token rows)."""
+    rc = _lib_().vtp_gemm_tn(_p(a), lda, _p(b), ldb, _p(c), ldc, ldc2, _p(resid), M, N, K, epi, a_remap[0], a_remap[1],
+                             b_remap[0], b_remap[1], c_remap[0], c_remap[1], splits, _s())
+    _lib.check(rc, "vtp_gemm_tn")
+
+
+def colsum_bf16(inp, ld, out, R, C, swiglu_h=0, in_remap=(0, 0)):
+    _lib.check(_lib_().vtp_colsum_bf16(_p(inp), ld, _p(out), swiglu_h, in_remap[0], in_remap[1], R, C, _s()), "vtp_colsum_bf16")
+
+
 def gemm_splits(K, splits):
     return _lib_().vtp_gemm_splits(K, splits)
 
