@@ -457,7 +457,8 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
-  int cfg = g_force_cfg >= 0 ? g_force_cfg : ((M >= 256 && splits > 1) ? 3 : 5);
+  // tools/gemm_tn_bench.py on MI355X: the 8-wave 128x128 tile wins on every wgrad shape (transpose reads want more waves)
+  int cfg = g_force_cfg >= 0 ? g_force_cfg : 5;
   if (cfg != 2 && cfg != 3 && cfg != 5) cfg = 0;
   hipStream_t s = (hipStream_t)stream;
   if (epilogue == VTP_EPI_F32) return launch_gemm<EPI_F32, true>(a, 1, cfg, s);

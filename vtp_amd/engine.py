@@ -197,7 +197,13 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
 
+import os as _os_mod
+
 BF, F32 = torch.bfloat16, torch.float32
+
+
+def _env_flag(name: str, default: str = "1") -> bool:
+    return _os_mod.environ.get(name, default) not in ("0", "false", "off")
 
 
 class Overlap:
@@ -205,7 +211,7 @@ class Overlap:
     reduce) is independent of dX, so it runs concurrently with the dgrad GEMM and fills the CUs that the other kernel's
     tail leaves idle.  fork/join are event waits (captured as parallel hipGraph branches under stream capture)."""
 
-    enabled = True
+    enabled = _env_flag("VTP_OVERLAP")  # VTP_OVERLAP=0: run the dW branch in-line (clean per-kernel profiles)
 
     def __init__(self):
         self.side = None
