@@ -195,8 +195,8 @@ class VTPTrainer:
                 txt_all = cw.get("txt_all", (Bg, Dt), F32)
 
                 def gather():
-                    dist.all_gather_into_tensor(img_all, img_n, group=self.group)
-                    dist.all_gather_into_tensor(txt_all, txt_n, group=self.group)
+                    self._all_gather_rows(img_all, img_n)
+                    self._all_gather_rows(txt_all, txt_n)
                 yield gather
             else:
                 img_all, txt_all = img_n, txt_n
@@ -212,8 +212,8 @@ class VTPTrainer:
                 rs_t = cw.get("rs_t", (B, Dt), F32)
 
                 def scatter():
-                    dist.reduce_scatter_tensor(rs_i, d_img_all, group=self.group)
-                    dist.reduce_scatter_tensor(rs_t, d_txt_all, group=self.group)
+                    self._reduce_scatter_rows(rs_i, d_img_all)
+                    self._reduce_scatter_rows(rs_t, d_txt_all)
                 yield scatter
             else:
                 rs_i, rs_t = d_img_all, d_txt_all
@@ -241,6 +241,31 @@ class VTPTrainer:
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         st.prep()
+
+    # feature exchange: RCCL all-gather / reduce-scatter; on backends without them (gloo, used by the single-GPU
+    # two-process test) the same result is formed with all_reduce
+    def _native_collectives(self) -> bool:
+        return self.bucketer.dist.get_backend(self.group) == "nccl"
+
+    def _all_gather_rows(self, out: torch.Tensor, inp: torch.Tensor):
+        dist = self.bucketer.dist
+        if self._native_collectives():
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+        else:
+            B = inp.shape[0]
+            out.zero_()
+            out[self.rank * B:(self.rank + 1) * B].copy_(inp)
+            dist.all_reduce(out, group=self.group)
+
+    def _reduce_scatter_rows(self, out: torch.Tensor, inp: torch.Tensor):
+        dist = self.bucketer.dist
+        if self._native_collectives():
+            dist.reduce_scatter_tensor(out, inp, group=self.group)
+        else:
+            B = out.shape[0]
+            tmp = inp.clone()
+            dist.all_reduce(tmp, group=self.group)
+            out.copy_(tmp[self.rank * B:(self.rank + 1) * B])
 
     def _set_hyper(self):
         self.step_no += 1
