@@ -104,6 +104,10 @@ int vtp_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, float* 
                        int in_pre, int R, int C, void* stream);
 /* out[c'] += sum_r in[r, c] for a bf16 [R, C] matrix (bias gradient); same column / row remaps as vtp_transpose_bf16. */
 int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_swiglu_h, int in_grp, int in_pre, int R, int C, void* stream);
+/* backward of vtp_assemble_tokens' mask substitution: for masked patch rows d_mask_token += dx[row] and dx_bf16[row] = 0
+ * (so the patch-embed wgrad / bias-grad skip them).  dx f32 / dx_bf16 [B*N, D], masks uint8 [B, N-1]. */
+int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N, int D,
+                      void* stream);
 /* out[d] += sum_b in[b*stride + d], f32 (gradient of the broadcast cls token, vision_transformer.py:210-217). */
 int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream);
 
@@ -139,6 +143,7 @@ int vtp_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, lo
 int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n, int accumulate, void* stream);
 /* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
 int vtp_ema(float* t, const float* s, long n, float momentum, void* stream);
+int vtp_ema_dev(float* t, const float* s, long n, const float* momentum /* device scalar */, void* stream);
 
 /* ---- CLIP text-tower glue + contrastive head (fp32; clip.hip) -------------------------------------------------
  * embed: x f32 [B*T, D] = table[ids] + pos (modeling_vtp.py:296-297); eot[b] = argmax_t ids[b,t] (text_global_pool
@@ -162,6 +167,28 @@ int vtp_clip_loss(const float* img_local, const float* txt_local, const float* i
                   const float* logit_scale, int B_local, int B_all, int D, int label_offset, float* loss_sum,
                   float* d_img_local, float* d_txt_local, float* d_img_all, float* d_txt_all, float* d_logit_scale,
                   float* scratch, void* stream);
+
+/* ---- self-supervised (DINO / iBOT) head (ssl.hip) -----------------------------------------------------------
+ * Token buffers of VTP.get_teacher_forward_outputs / get_student_ssl_outputs (vtp.py:432-439,470-473):
+ * dst bf16 [T, D] row t = src row idx[t] (idx[t] < 0: zero row); scatter is the backward (indices are unique). */
+int vtp_gather_token_rows(const void* src, const int* idx, void* dst, int T, int D, void* stream);
+int vtp_scatter_token_rows(const void* d_dst, const int* idx, void* d_src, int T, int D, void* stream);
+/* weight_norm(Linear(C -> K, bias=False)) of DINOHead.last_layer (dino_head.py:47-49): weff bf16 [K,C] = g * v / ||v||_row,
+ * weffT bf16 [C,K] (optional), inv_norm f32 [K] = 1/||v||.  bwd: given dW_eff f32 [K,C]: dv += ..., dg += <dW, v/||v||>. */
+int vtp_weight_norm_prep(const float* v, const float* g, void* weff, void* weffT, float* inv_norm, int K, int C, void* stream);
+int vtp_weight_norm_bwd(const float* dW, const float* v, const float* g, const float* inv_norm, float* dv, float* dg, int K, int C,
+                        void* stream);
+/* teacher targets: probs bf16 [T,K] = softmax((logits - center) * inv_temp) row-wise (center f32 [K] or NULL). */
+int vtp_softmax_center(const void* logits, const float* center, float inv_temp, void* probs, int T, int K, void* stream);
+/* student cross-entropy (DINO cls / iBOT patch loss; OUR spec, DINOv2 convention): for student row r with teacher target rows
+ * t_idx0[r], t_idx1[r] (-1 = none; t_idx0 < 0 or row_weight 0 = padding row):
+ *   loss_sum += w_r * sum_targets( -sum_k p_t[k] * log_softmax(s_r * inv_temp)[k] ),
+ *   d_student_logits[r] = w_r * inv_temp * (n_targets * softmax(s_r * inv_temp) - sum_targets p_t)     (bf16). */
+int vtp_dino_ce(const void* student_logits, const void* teacher_probs, const int* t_idx0, const int* t_idx1,
+                const float* row_weight, float inv_temp, float* loss_sum, void* d_student_logits, int T, int K, void* stream);
+/* center = momentum * center + (1 - momentum) * col_sum * inv_count   (teacher-output centering, f32 [K]). */
+int vtp_center_ema(float* center, const float* col_sum, float inv_count, const float* count_ptr, float momentum, int K,
+                   void* stream);  /* count_ptr != NULL: inv_count = 1 / max(*count_ptr, 1) read on the device */
 
 #ifdef __cplusplus
 }

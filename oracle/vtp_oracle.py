@@ -274,6 +274,75 @@ def rec_clip_train_loss(sd, img, text, vis_heads, dec_heads, txt_heads) -> Tuple
     return l1, clip_loss(i, t, sd["logit_scale"].exp())
 
 
+# --------------------------------------------------------------------------------------------
+# SSL branch -- DINO head (dino_head.py), teacher/student token buffers (vtp.py:410-484); losses are OUR spec
+# --------------------------------------------------------------------------------------------
+def dino_head_forward(sd, pre: str, x: Tensor) -> Tensor:
+    """DINOHead.forward (dino_head.py:65-89): MLP -> F.normalize(eps=1e-12) -> weight-normed linear
+    (W = g * v / ||v||_row, torch.nn.utils.weight_norm dim=0; dino_head.py:47-49)."""
+    h = F.gelu(F.linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"]))
+    h = F.gelu(F.linear(h, sd[pre + "mlp.2.weight"], sd[pre + "mlp.2.bias"]))
+    z = F.linear(h, sd[pre + "mlp.4.weight"], sd[pre + "mlp.4.bias"])
+    z = F.normalize(z, dim=-1, p=2, eps=1e-12)
+    v, g = sd[pre + "last_layer.weight_v"], sd[pre + "last_layer.weight_g"]
+    return F.linear(z, g * v / v.norm(dim=1, keepdim=True))
+
+
+def ssl_outputs(sd, global_crops, local_crops, masks, vis_heads: int):
+    """VTP.get_teacher_forward_outputs + get_student_ssl_outputs (vtp.py:410-484) for bottleneck_ae_only=True and
+    drop rates 0.  The student's two resolutions go through the same trunk weights; batching them in one list call
+    (block.py:235-298) is an efficiency device only, so they are evaluated as two passes here."""
+    idx = masks.flatten().nonzero().flatten()
+    with torch.no_grad():
+        t = trunk_forward(sd, global_crops, vis_heads, use_bottleneck=False, pre="teacher_trunk.")
+        cls = t["x_norm_clstoken"].chunk(2)
+        cls = torch.cat((cls[1], cls[0]))                                   # vtp.py:425-426
+        patches = t["x_norm_patchtokens"].flatten(0, 1)[idx]
+        th = dino_head_forward(sd, "teacher_dino_head.", torch.cat([cls, patches]))
+    n_cls = cls.shape[0]
+    teacher = {"teacher_cls_tokens_after_head": th[:n_cls], "masked_teacher_patch_tokens_after_head": th[n_cls:]}
+    sg = trunk_forward(sd, global_crops, vis_heads, use_bottleneck=False, masks=masks)
+    sl = trunk_forward(sd, local_crops, vis_heads, use_bottleneck=False)
+    student = {"student_local_cls_tokens_after_head": dino_head_forward(sd, "dino_head.", sl["x_norm_clstoken"]),
+               "student_global_cls_tokens_after_head": dino_head_forward(sd, "dino_head.", sg["x_norm_clstoken"]),
+               "student_global_cls_tokens": sg["x_norm_clstoken"],
+               "student_global_masked_patch_tokens_after_head":
+                   dino_head_forward(sd, "dino_head.", sg["x_norm_patchtokens"].flatten(0, 1)[idx])}
+    return teacher, student
+
+
+def ssl_loss(t_out, s_out, masks, center_dino, center_ibot, n_local: int, student_temp: float = 0.1,
+             teacher_temp: float = 0.07, dino_weight: float = 1.0, ibot_weight: float = 1.0) -> Tensor:
+    """OUR SSL loss spec (DINOv2 conventions; the reference ships none -> parity unpinned):
+      teacher targets  p = softmax((z_t - center) / teacher_temp)            (separate centres for cls / patch tokens)
+      DINO  = [ sum_{local crop j, view v} mean_b CE(s_loc[j,b], p[v,b]) + sum_v mean_b CE(s_glob[v,b], p[other(v),b]) ]
+              / (n_g (n_g - 1) + n_local n_g)            with the teacher cls rows already view-swapped (vtp.py:425-426)
+      iBOT  = (1 / B) sum_masked tokens CE(s_patch, p_patch) / n_masked_in_image
+    Returns dino_weight * DINO + ibot_weight * iBOT."""
+    tc = t_out["teacher_cls_tokens_after_head"].detach()
+    tp = t_out["masked_teacher_patch_tokens_after_head"].detach()
+    B2 = tc.shape[0]
+    B = B2 // 2
+    p_cls = F.softmax((tc - center_dino) / teacher_temp, dim=-1)
+    lsm_g = F.log_softmax(s_out["student_global_cls_tokens_after_head"] / student_temp, dim=-1)
+    lsm_l = F.log_softmax(s_out["student_local_cls_tokens_after_head"] / student_temp, dim=-1)
+    terms = 2 * 1 + n_local * 2
+    dino = -(p_cls * lsm_g).sum(-1).sum() / B               # sum over the two views of mean_b
+    lsm_l = lsm_l.view(n_local, B, -1)
+    for v in range(2):
+        dino = dino - (p_cls[v * B:(v + 1) * B][None] * lsm_l).sum(-1).sum() / B
+    dino = dino / terms
+    ibot = torch.zeros(())
+    if tp.shape[0] > 0:
+        p_pat = F.softmax((tp - center_ibot) / teacher_temp, dim=-1)
+        lsm_p = F.log_softmax(s_out["student_global_masked_patch_tokens_after_head"] / student_temp, dim=-1)
+        per_img = masks.sum(1).clamp(min=1)
+        img_of = masks.nonzero()[:, 0]
+        w = 1.0 / per_img[img_of].float()
+        ibot = -((p_pat * lsm_p).sum(-1) * w).sum() / B
+    return dino_weight * dino + ibot_weight * ibot
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, b1: float, b2: float,
                eps: float, wd: float) -> None:
     """torch.optim.AdamW semantics (decoupled weight decay), in place, fp32."""

@@ -1,0 +1,220 @@
+"""Self-supervised (DINO / iBOT) branch on the MI355X: kernels vs PyTorch, vtp_amd.VTP vs the golden outputs / gradients of
+the reference's legacy training class (tests/golden/vtp_tiny_ssl.safetensors, oracle/make_golden_ssl.py), EMA teacher,
+and the full rec + clip + ssl step (eager == hipGraph segments)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.fixture(scope="module")
+def sslg():
+    from safetensors.torch import load_file
+    g = load_file(os.path.join(ROOT, "tests", "golden", "vtp_tiny_ssl.safetensors"))
+    return g, {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relF(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build_vtp(sd):
+    from oracle.make_golden_ssl import SSL_CFG as C
+    from vtp_amd import VTP, VTPConfig
+    cfg = VTPConfig(image_size=C["R"], vision_embed_dim=C["embed_dim"], vision_depth=C["depth"], vision_num_heads=C["heads"],
+                    text_embed_dim=128, text_depth=1, text_num_heads=2, text_vocab_size=64, text_context_length=8,
+                    decoder_embed_dim=128, decoder_depth=1, decoder_num_heads=2)
+    m = VTP(cfg, dino_out_dim=C["K"], dino_hidden_dim=C["hidden"], dino_bottleneck_dim=C["bott"])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(not k.startswith(("trunk.", "dino_head.", "teacher_")) for k in missing), missing
+    return m.to(DEV)
+
+
+def test_ssl_kernels_vs_torch():
+    from vtp_amd import ops as o
+    g = torch.Generator(device=DEV).manual_seed(31)
+    # gather / scatter of token rows
+    src = bf(torch.randn(50, 128, device=DEV, generator=g))
+    idx = torch.tensor([3, -1, 49, 0, 7, -1, 20, 21], dtype=torch.int32, device=DEV)
+    dst = torch.full((8, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.gather_token_rows(src, idx, dst, 8, 128)
+    ref = torch.where((idx >= 0)[:, None], src[idx.clamp(min=0).long()], torch.zeros_like(dst))
+    assert torch.equal(dst, ref)
+    back = torch.zeros_like(src)
+    o.scatter_token_rows(dst, idx, back, 8, 128)
+    ref_b = torch.zeros_like(src)
+    ref_b[idx[idx >= 0].long()] = dst[idx >= 0]
+    assert torch.equal(back, ref_b)
+    # weight norm
+    K, C = 515, 64
+    v = torch.randn(K, C, device=DEV, generator=g) * 0.02
+    gg = torch.rand(K, device=DEV, generator=g) + 0.5
+    weff = torch.empty(K, C, dtype=torch.bfloat16, device=DEV)
+    weffT = torch.empty(C, K, dtype=torch.bfloat16, device=DEV)
+    inv = torch.empty(K, device=DEV)
+    o.weight_norm_prep(v, gg, weff, weffT, inv, K, C)
+    vr, gr = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    wr = gr[:, None] * vr / vr.norm(dim=1, keepdim=True)
+    assert torch.equal(weff, bf(wr.detach())) and torch.equal(weffT, weff.T)
+    dW = torch.randn(K, C, device=DEV, generator=g)
+    wr.backward(dW)
+    dv, dg = torch.ones_like(v), torch.ones_like(gg)
+    o.weight_norm_bwd(dW, v, gg, inv, dv, dg, K, C)
+    assert relF(dv, 1 + vr.grad) < 1e-5 and relF(dg, 1 + gr.grad) < 1e-5
+    # teacher softmax-centre + student CE (two targets, one target, padding rows)
+    Kp, Tt, Ts = 4096, 6, 9
+    tl = bf(torch.randn(Tt, Kp, device=DEV, generator=g) * 2)
+    center = torch.randn(Kp, device=DEV, generator=g) * 0.1
+    probs = torch.empty(Tt, Kp, dtype=torch.bfloat16, device=DEV)
+    o.softmax_center(tl, center, 1 / 0.07, probs, Tt, Kp)
+    pref = F.softmax((tl.float() - center) / 0.07, dim=-1)
+    assert float((probs.float() - pref).abs().max()) < 2 ** -8 * float(pref.max()) + 1e-6
+    sl = bf(torch.randn(Ts, Kp, device=DEV, generator=g) * 2)
+    t0 = torch.tensor([0, 1, 2, 3, 4, 5, 0, -1, 2], dtype=torch.int32, device=DEV)
+    t1 = torch.tensor([3, 4, -1, -1, -1, 0, -1, -1, -1], dtype=torch.int32, device=DEV)
+    w = torch.tensor([0.5, 0.25, 1.0, 0.125, 0.3, 0.7, 0.0, 0.9, 0.2], device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    dS = torch.full((Ts, Kp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.dino_ce(sl, probs, t0, t1, w, 10.0, loss, dS, Ts, Kp)
+    sr = sl.float().requires_grad_(True)
+    lsm = F.log_softmax(sr * 10.0, dim=-1)
+    tot = 0.0
+    for r in range(Ts):
+        if w[r] == 0 or t0[r] < 0:
+            continue
+        q = probs[t0[r]].float() + (probs[t1[r]].float() if t1[r] >= 0 else 0.0)
+        tot = tot - w[r] * (q * lsm[r]).sum()
+    tot.backward()
+    assert abs(float(loss) - float(tot)) < 1e-4 * abs(float(tot))
+    assert relF(dS, sr.grad) < 6e-3, relF(dS, sr.grad)
+    assert float(dS[6].float().abs().max()) == 0.0 and float(dS[7].float().abs().max()) == 0.0  # padding rows
+    # centre EMA with a device-side count; mask-row backward
+    c = torch.randn(Kp, device=DEV, generator=g)
+    cs = torch.randn(Kp, device=DEV, generator=g)
+    cnt = torch.tensor([5.0], device=DEV)
+    refc = 0.9 * c + 0.1 * cs / 5.0
+    o.center_ema(c, cs, 0.0, 0.9, Kp, count=cnt)
+    assert relF(c, refc) < 1e-6
+    B, N, D = 3, 6, 128
+    dx = torch.randn(B * N, D, device=DEV, generator=g)
+    dxb = bf(dx)
+    masks = (torch.rand(B, N - 1, device=DEV, generator=g) < 0.5).to(torch.uint8)
+    dm = torch.ones(D, device=DEV)
+    ref_dm = 1 + dx.view(B, N, D)[:, 1:][masks.bool()].sum(0)
+    ref_dxb = dxb.clone().view(B, N, D)
+    ref_dxb[:, 1:][masks.bool()] = 0
+    o.mask_rows_bwd(dx, dxb, masks, dm, B, N, D)
+    assert relF(dm, ref_dm) < 1e-6 and torch.equal(dxb.view(B, N, D), ref_dxb)
+
+
+def test_ssl_forward_vs_reference_legacy_class(sslg):
+    """VTP.forward_ssl_learning (legacy signature) vs the outputs of the reference's VTP(forward_type='ssl')."""
+    from oracle import vtp_oracle as O
+    from oracle.make_golden_ssl import SSL_CFG as C
+    g, sd = sslg
+    m = build_vtp(sd)
+    masks = g["in.masks"].bool()
+    idx = masks.flatten().nonzero().flatten()
+    t_out, s_out = m.forward_ssl_learning(g["in.global_crops"].to(DEV), 2, idx, int(idx.numel()), int(idx.numel()) + 5,
+                                          g["in.local_crops"].to(DEV), masks)
+    # noise floor: the oracle under bf16 autocast vs fp32
+    with torch.no_grad():
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            t_b, s_b = O.ssl_outputs(sd, g["in.global_crops"], g["in.local_crops"], masks, C["heads"])
+    for k in ("teacher_cls_tokens_after_head", "masked_teacher_patch_tokens_after_head"):
+        e, e_ref = relF(t_out[k], g["teacher." + k]), relF(t_b[k], g["teacher." + k])
+        print(f"teacher {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
+        assert e <= max(1.5 * e_ref, 1e-2), k
+    for k in ("student_local_cls_tokens_after_head", "student_global_cls_tokens_after_head", "student_global_cls_tokens",
+              "student_global_masked_patch_tokens_after_head"):
+        e, e_ref = relF(s_out[k], g["student." + k]), relF(s_b[k], g["student." + k])
+        print(f"student {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
+        assert e <= max(1.5 * e_ref, 1e-2), k
+    assert t_out["n_masked_patches"] == int(idx.numel())
+
+
+def test_ssl_step_gradients_vs_reference_autograd(sslg):
+    """DINO + iBOT loss (our spec) through the student trunk (masked global + local crops) and the DINO head: gradients vs
+    the reference's autograd (golden), loss value, centre update, EMA teacher."""
+    from oracle import vtp_oracle as O
+    from oracle.make_golden_ssl import SSL_CFG as C, SSL_GRAD_KEYS
+    from vtp_amd import VTPTrainer
+    g, sd = sslg
+    m = build_vtp(sd)
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0, rec_weight=0.0, teacher_momentum=0.9)
+    tr.center_dino.copy_(g["in.center_dino"])
+    tr.center_ibot.copy_(g["in.center_ibot"])
+    masks = g["in.masks"].bool()
+    ssl = tr.prepare_ssl(g["in.global_crops"].to(DEV), g["in.local_crops"].to(DEV), masks)
+    img = torch.randn(C["B"], 3, C["R"], C["R"], device=DEV)
+    teacher_before = m._engine().p("teacher_trunk.norm.weight").clone()
+    tr.step(img, None, ssl)
+    torch.cuda.synchronize()
+    loss = float(tr.ssl_loss_sum)
+    print(f"ssl loss {loss:.4f} (golden {float(g['out.ssl_loss']):.4f})")
+    assert abs(loss - float(g["out.ssl_loss"])) < 1e-2 * float(g["out.ssl_loss"])
+    # noise floor from the oracle's bf16-autocast backward
+    sdr = {k: v.clone().requires_grad_(v.dtype == torch.float32 and not k.startswith("teacher_")) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        t_b, s_b = O.ssl_outputs(sdr, g["in.global_crops"], g["in.local_crops"], masks, C["heads"])
+        O.ssl_loss(t_b, s_b, masks, g["in.center_dino"], g["in.center_ibot"], n_local=C["n_local"]).backward()
+    params = dict(m.named_parameters())
+    for k in SSL_GRAD_KEYS:
+        ref = g["grad." + k]
+        e, e_ref = relF(params[k].grad, ref), relF(sdr[k].grad, ref)
+        print(f"ssl grad {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
+        assert e <= max(1.5 * e_ref, 3e-2) and e < 0.1, k
+    # centre update: c = 0.9 c + 0.1 mean(teacher logits)
+    tc = g["teacher.teacher_cls_tokens_after_head"]
+    ref_c = 0.9 * g["in.center_dino"] + 0.1 * tc.mean(0)
+    assert relF(tr.center_dino, ref_c) < 2e-2
+    # EMA teacher ran after the (lr = 0) optimizer step: teacher = 0.9 teacher + 0.1 student
+    ref_t = 0.9 * teacher_before + 0.1 * m._engine().p("trunk.norm.weight")
+    assert relF(m._engine().p("teacher_trunk.norm.weight"), ref_t) < 1e-6
+    m.update_teacher(0.5)
+    assert relF(m._engine().p("teacher_trunk.norm.weight"), 0.5 * ref_t + 0.5 * m._engine().p("trunk.norm.weight")) < 1e-6
+    assert len(m.get_ssl_params()) == 8
+
+
+def test_full_step_rec_clip_ssl_graphs_match_eager(sslg):
+    from oracle.make_golden_ssl import SSL_CFG as C
+    from vtp_amd import VTPTrainer
+    g, sd = sslg
+    img = torch.randn(C["B"], 3, C["R"], C["R"], device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    txt = torch.randint(1, 60, (C["B"], 8), device=DEV)
+    txt[:, 5] = 63
+    res = []
+    for use_graphs in (False, True):
+        torch.manual_seed(0)
+        m = build_vtp(sd)
+        tr = VTPTrainer(m, lr=5e-4, weight_decay=0.0, use_graphs=use_graphs)
+        ssl = tr.prepare_ssl(g["in.global_crops"].to(DEV), g["in.local_crops"].to(DEV), g["in.masks"].bool())
+        hist = []
+        for _ in range(4):
+            r, c = tr.step(img, txt, ssl)
+            hist.append((float(r), float(c), float(tr.ssl_loss_sum)))
+        res.append((hist, m._engine().flat_p.clone()))
+    print("eager:", res[0][0])
+    print("graph:", res[1][0])
+    for a, b in zip(res[0][0], res[1][0]):
+        for x, y in zip(a, b):
+            assert abs(x - y) < 2e-3 * abs(x) + 1e-5
+    assert res[0][0][-1][2] < res[0][0][0][2], "SSL loss must decrease"
+    assert relF(res[1][1], res[0][1]) < 1e-3

@@ -10,6 +10,9 @@ def __getattr__(name):  # lazy: importing the package must not require torch.cud
     if name == "VTPModel":
         from .model import VTPModel
         return VTPModel
+    if name == "VTP":
+        from .vtp import VTP
+        return VTP
     if name == "VTPTrainer":
         from .train import VTPTrainer
         return VTPTrainer

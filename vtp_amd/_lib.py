@@ -21,6 +21,7 @@ SIGNATURES = {
     "vtp_assemble_tokens": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_transpose_bf16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],  # in ld out ld colsum swiglu_h in_grp in_pre R C stream
     "vtp_strided_rowsum": [_P, _L, _P, _I, _I, _P],
+    "vtp_mask_rows_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_cast_f32_bf16": [_P, _P, _L, _P],
     "vtp_cast_transpose_f32_bf16": [_P, _P, _I, _I, _P],
     "vtp_prep_weights": [_P, _I, _I, _P],
@@ -36,6 +37,14 @@ SIGNATURES = {
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],
+    "vtp_gather_token_rows": [_P, _P, _P, _I, _I, _P],
+    "vtp_scatter_token_rows": [_P, _P, _P, _I, _I, _P],
+    "vtp_weight_norm_prep": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "vtp_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vtp_softmax_center": [_P, _P, _F, _P, _I, _I, _P],
+    "vtp_dino_ce": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
+    "vtp_center_ema": [_P, _P, _F, _P, _F, _I, _P],
+    "vtp_ema_dev": [_P, _P, _L, _P, _P],
     "vtp_embed_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_embed_tokens_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_gather_rows": [_P, _P, _P, _I, _I, _I, _P],

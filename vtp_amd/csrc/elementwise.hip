@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, float mom) {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, float mom,
+                                                  const float* __restrict__ mom_ptr) {
+  if (mom_ptr) mom = mom_ptr[0];  // device-resident momentum: graph replays follow the teacher-momentum schedule
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
     f32x4 tv = *(const f32x4*)(t + 4 * i), sv = *(const f32x4*)(s + 4 * i);
@@ -385,6 +387,24 @@ __global__ __launch_bounds__(256) void strided_rowsum_kernel(const float* __rest
   float s = 0.f;
   for (int b = 0; b < B; ++b) s += in[(long)b * stride + d];
   out[d] += s;
+}
+
+// backward of the mask-token substitution (vision_transformer.py:195): rows whose patch embedding was replaced by
+// mask_token send their gradient to mask_token and nothing to the patch embedding.  thread = one feature column.
+__global__ __launch_bounds__(256) void mask_rows_bwd_kernel(const float* __restrict__ dx, bf16* __restrict__ dxb,
+                                                            const unsigned char* __restrict__ masks, float* __restrict__ d_mask,
+                                                            int B, int N, int D) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int n = 1; n < N; ++n)
+      if (masks[(long)b * (N - 1) + (n - 1)]) {
+        const long o = ((long)b * N + n) * D + d;
+        s += dx[o];
+        dxb[o] = (bf16)0.f;
+      }
+  d_mask[d] += s;
 }
 
 static inline int grid_for(long items, int cap = 4096) {
@@ -445,6 +465,14 @@ extern "C" int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_sw
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld,
                      out, R, C, colsum_swiglu_h, in_grp, in_pre);
   return check_launch("colsum_bf16");
+}
+
+extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,
+                                 int D, void* stream) {
+  VTP_REQUIRE(dx && dx_bf16 && masks && d_mask_token && B > 0 && N > 1 && D > 0, "vtp_mask_rows_bwd: bad argument");
+  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, dx, (bf16*)dx_bf16, masks,
+                     d_mask_token, B, N, D);
+  return check_launch("mask_rows_bwd");
 }
 
 extern "C" int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream) {
@@ -526,6 +554,12 @@ extern "C" int vtp_reduce_slabs(const float* slabs, long stride, int S, float* d
 
 extern "C" int vtp_ema(float* t, const float* s, long n, float momentum, void* stream) {
   VTP_REQUIRE(t && s && n > 0 && n % 4 == 0, "vtp_ema: bad argument (n %% 4 == 0)");
-  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, t, s, n, momentum);
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, t, s, n, momentum, (const float*)nullptr);
   return check_launch("ema");
+}
+
+extern "C" int vtp_ema_dev(float* t, const float* s, long n, const float* momentum, void* stream) {
+  VTP_REQUIRE(t && s && momentum && n > 0 && n % 4 == 0, "vtp_ema_dev: bad argument (n %% 4 == 0)");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, t, s, n, 0.f, momentum);
+  return check_launch("ema_dev");
 }

@@ -165,6 +165,8 @@ class ParamStore:
     def prep(self):
         """Refresh every bf16 compute copy from the fp32 masters (one kernel launch)."""
         ops.prep_weights(self._desc_dev, self._ndesc, self._tiles)
+        for hook in getattr(self, "prep_hooks", ()):
+            hook()
         self._prepped_version = self.flat_p._version
 
     def ensure_fresh(self):
@@ -360,6 +362,7 @@ class Stack:
         M = B * N
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
+        saved_all = []
         for i, b in enumerate(self.blocks):
             t = f"{i}." if train else ""
             xn1 = ws.get(t + "xn1", (M, D), BF)
@@ -373,7 +376,7 @@ class Stack:
             pre = ws.get(t + "x12", (M, 2 * H if vit else H), BF) if train else None  # FFN pre-activations
             hid = ws.get(t + "hid", (M, H), BF)
             xout = ws.get((f"{i}.xout" if train else f"xout{i & 1}"), (M, D), F32)
-            b.x_in = x if train else None  # block input (previous block's xout buffer) is kept for norm1 backward
+            x_in = x  # block input (previous block's xout buffer) is kept for norm1 backward
 
             ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
             ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
@@ -388,12 +391,13 @@ class Stack:
                 ops.gemm_nt(xn2, b.fc.w, hid, M=M, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias, epi=EPI_GELU)
             ops.gemm_nt(hid, b.w3.w, xout, M=M, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, resid=xmid, epi=EPI_F32)
             if train:
-                b.saved = (xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid)
+                saved_all.append((x_in, xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid))
             x = xout
+        self.last_saved = saved_all  # per-call context: several forward passes may be in flight before their backward
         return x
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
-    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int):
+    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None):
         """Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
         gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input."""
         D, H, heads = self.D, self.H, self.heads
@@ -408,10 +412,11 @@ class Stack:
         delta = ws.get("b.delta", (B, heads, N), F32)
         dmid = ws.get("b.dmid", (M, D), F32)
         dmid_b = ws.get("b.dmid_b", (M, D), BF)
+        saved = self.last_saved if saved is None else saved
         for i in range(self.depth - 1, -1, -1):
             b = self.blocks[i]
             assert b.ls1 is None and b.ls2 is None, "LayerScale backward is not implemented"
-            xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid = b.saved
+            x_in, xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid = saved[i]
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
             # ---- FFN: x_out = x_mid + w3(act(...))
@@ -431,7 +436,7 @@ class Stack:
             if rope is not None:
                 ops.rope_qk(dqkv, rope[0], rope[1], B, N, heads, prefix_tokens, inverse=True)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
-            ops.norm_bwd(dxn, b.x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
+            ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
             dy, dy_b = dxo, dxo_b
             OVERLAP.join()
             yield ("block", i)
@@ -468,85 +473,94 @@ def rope_tables(periods: torch.Tensor, H: int, W: int, device) -> Tuple[torch.Te
 # ViT trunk with bottleneck (vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79)
 # =====================================================================================================================
 class TrunkEngine:
-    def __init__(self, store: ParamStore, cfg, periods: torch.Tensor):
+    def __init__(self, store: ParamStore, cfg, periods: torch.Tensor, prefix: str = "trunk."):
         from .config import swiglu_hidden
         self.store = store
+        self.prefix = prefix  # "trunk." (student) or "teacher_trunk." (EMA teacher, vtp.py:253-268)
         self.D, self.heads, self.depth = cfg.vision_embed_dim, cfg.vision_num_heads, cfg.vision_depth
         self.H = swiglu_hidden(self.D, cfg.vision_mlp_ratio)
         self.kind = ops.NORM_RMS if cfg.vision_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
         self.periods = periods.detach().to("cpu")  # host copy: rope_tables must not touch the device during graph capture
-        self.pe = store.lin("trunk.patch_embed.proj.weight", "trunk.patch_embed.proj.bias", self.D, 768, need_T=False)
-        self.stack = Stack(store, "trunk.blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
+        self.pe = store.lin(self.prefix + "patch_embed.proj.weight", self.prefix + "patch_embed.proj.bias", self.D, 768, need_T=False)
+        self.stack = Stack(store, self.prefix + "blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
         self.bott_dim = cfg.vision_feature_bottleneck
-        self.bott = store.lin("trunk.feature_bottleneck.weight", None, self.bott_dim, self.D) \
-            if store.has("trunk.feature_bottleneck.weight") else None
+        self.bott = store.lin(self.prefix + "feature_bottleneck.weight", None, self.bott_dim, self.D) \
+            if store.has(self.prefix + "feature_bottleneck.weight") else None
         self.ws: Dict[tuple, Workspace] = {}
 
-    def workspace(self, B, Hh, Ww) -> Workspace:
-        key = (B, Hh, Ww)
+    def workspace(self, B, Hh, Ww, tag: str = "") -> Workspace:
+        key = (B, Hh, Ww, tag)
         if key not in self.ws:
             self.ws[key] = Workspace(self.store.device)
         return self.ws[key]
 
-    def forward(self, img: torch.Tensor, train: bool, masks: Optional[torch.Tensor] = None):
-        """img f32 [B,3,H,W] -> final-norm tokens xnf bf16 [B*N, D] (N = 1 + hw)."""
+    def forward(self, img: torch.Tensor, train: bool, masks: Optional[torch.Tensor] = None, tag: str = ""):
+        """img f32 [B,3,H,W] -> final-norm tokens xnf bf16 [B*N, D] (N = 1 + hw).  masks: uint8 [B, hw] (1 = replace the
+        patch embedding by mask_token, vision_transformer.py:194-196).  `tag` separates the buffers of passes that are in
+        flight at the same time with the same shape; self.ctx() returns the handle backward() needs for such passes."""
         st = self.store
         B, _, Hh, Ww = img.shape
         h, w = Hh // 16, Ww // 16
         hw, N, D = h * w, h * w + 1, self.D
         M = B * N
-        ws = self.workspace(B, Hh, Ww)
+        ws = self.workspace(B, Hh, Ww, tag)
         patches = ws.get("patches", (B * hw, 768), BF)
         x0 = ws.get("x0", (M, D), F32)
         ops.im2col16(img, patches, B, Hh, Ww)
         ops.gemm_nt(patches, self.pe.w, x0, M=B * hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(hw, 1))
-        ops.assemble_tokens(x0, st.p("trunk.cls_token"), st.p("trunk.mask_token"), masks, B, N, D)
+        ops.assemble_tokens(x0, st.p(self.prefix + "cls_token"), st.p(self.prefix + "mask_token"), masks, B, N, D)
         rope = rope_tables(self.periods, h, w, st.device)
         xl = self.stack.forward(ws, x0, B, N, rope, 1, train)
         xnf = ws.get("xnf", (M, D), BF)
         stf = ws.get("stf", (M, 2), F32)
-        ops.norm_fwd(xl, st.p("trunk.norm.weight"), st.p("trunk.norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf,
+        ops.norm_fwd(xl, st.p(self.prefix + "norm.weight"), st.p(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf,
                      M, D, self.eps, self.kind)
-        self._ctx = (ws, B, h, w, xl, xnf, stf, rope, patches, masks)
+        self._ctx = (ws, B, h, w, xl, xnf, stf, rope, patches, masks, self.stack.last_saved, x0)
         return xnf
+
+    def ctx(self):
+        return self._ctx
 
     def latents(self, out_f32: bool = False) -> torch.Tensor:
         """bottleneck on the patch rows of the last forward -> [B*hw, 64] (bf16, or f32 for the API boundary)."""
-        ws, B, h, w, _, xnf, _, _, _, _ = self._ctx
+        ws, B, h, w, _, xnf = self._ctx[:6]
         hw = h * w
         lat = ws.get("lat32" if out_f32 else "lat", (B * hw, self.bott_dim), F32 if out_f32 else BF)
         ops.gemm_nt(xnf, self.bott.w, lat, M=B * hw, N=self.bott_dim, K=self.D, epi=EPI_F32 if out_f32 else EPI_BF16,
                     a_remap=(hw, 1))
         return lat
 
-    def d_xnf_buffer(self) -> torch.Tensor:
+    def d_xnf_buffer(self, ctx=None) -> torch.Tensor:
         """bf16 [B*N, D] gradient w.r.t. the final-norm tokens of the last forward.  Patch rows are written by
         backward() (bottleneck dgrad); cls rows are zero unless a cls-path head (CLIP) writes them before backward()."""
-        ws, B, h, w = self._ctx[:4]
+        ws, B, h, w = (self._ctx if ctx is None else ctx)[:4]
         return ws.get("b.d_xnf", (B * (h * w + 1), self.D), BF, zero=True)
 
-    def backward(self, d_lat: Optional[torch.Tensor]):
+    def backward(self, d_lat: Optional[torch.Tensor], ctx=None):
         """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g.
         Generator (see Stack.backward): yields "tail", then ("block", i) per block."""
         st = self.store
-        ws, B, h, w, xl, xnf, stf, rope, patches, masks = self._ctx
-        assert masks is None, "mask-token backward is not implemented yet"
+        if ctx is not None:
+            self._ctx = ctx
+        ws, B, h, w, xl, xnf, stf, rope, patches, masks, stack_saved, _ = self._ctx
         hw, N, D = h * w, h * w + 1, self.D
         M = B * N
-        d_xnf = ws.get("b.d_xnf", (M, D), BF, zero=True)  # cls rows stay zero unless a cls-path gradient is added
+        d_xnf = ws.get("b.d_xnf", (M, D), BF, zero=True)  # rows stay zero unless a head wrote them before backward()
         if d_lat is not None:
             linear_bwd(ws, "bott", self.bott, d_lat, xnf, B * hw, d_xnf, x_remap=(hw, 1), dx_remap=(hw, 1))
         dx = ws.get("b.dxt", (M, D), F32)
         dx_b = ws.get("b.dxt_b", (M, D), BF)
-        ops.norm_bwd(d_xnf, xl, st.p("trunk.norm.weight"), stf, None, dx, dx_b, st.g("trunk.norm.weight"),
-                     st.g("trunk.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
+        ops.norm_bwd(d_xnf, xl, st.p(self.prefix + "norm.weight"), stf, None, dx, dx_b, st.g(self.prefix + "norm.weight"),
+                     st.g(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, N, rope, 1)
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, N, rope, 1, stack_saved)
+        if masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
+            ops.mask_rows_bwd(dx0, dx0_b, masks, st.g(self.prefix + "mask_token"), B, N, D)
         # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
         linear_bwd(ws, "pe", self.pe, dx0_b, patches, B * hw, None, need_dx=False, dy_remap=(hw, 1))
-        ops.strided_rowsum(dx0, N * D, st.g("trunk.cls_token"), B, D)
+        ops.strided_rowsum(dx0, N * D, st.g(self.prefix + "cls_token"), B, D)
         OVERLAP.join()
 
 
@@ -589,14 +603,14 @@ class DecoderEngine:
                      st.p("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf, M, D, self.eps, self.kind)
         t = ws.get("t", (M, 768), BF)
         ops.gemm_nt(xnf, self.pout.w, t, M=M, N=768, K=D, bias=self.pout.bias, epi=EPI_BF16)
-        self._ctx = (ws, B, h, w, lat, xl, xnf, stf, rope)
+        self._ctx = (ws, B, h, w, lat, xl, xnf, stf, rope, self.stack.last_saved)
         return t
 
     def backward(self, dt: torch.Tensor):
         """dt bf16 [B*hw, 768] -> d_lat bf16 [B*hw, 64]; parameter grads accumulate into store.flat_g.
         Generator: yields "tail", then ("block", i) per block; returns d_lat."""
         st = self.store
-        ws, B, h, w, lat, xl, xnf, stf, rope = self._ctx
+        ws, B, h, w, lat, xl, xnf, stf, rope, stack_saved = self._ctx
         M, D = B * h * w, self.D
         d_xnf = ws.get("b.d_xnf", (M, D), BF)
         linear_bwd(ws, "pout", self.pout, dt, xnf, M, d_xnf)
@@ -606,7 +620,7 @@ class DecoderEngine:
                      st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0)
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, stack_saved)
         d_lat = ws.get("b.d_lat", (M, self.cin), BF)
         linear_bwd(ws, "pin", self.pin, dx0_b, lat, M, d_lat)
         OVERLAP.join()

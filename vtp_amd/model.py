@@ -210,10 +210,14 @@ class VTPModel(nn.Module):
                                      self.visual_proj.weight.shape[1])
                 self._text = TextEngine(st, self.config)
                 self._clip = ClipHead(st, self._vproj, self.config.vision_embed_dim, self.config.text_embed_dim)
+            self._build_extra_engines(st)
             st.finalize()
             self._store = st
             self._pver = self._param_version()
         return self._store
+
+    def _build_extra_engines(self, st):
+        """hook for subclasses (vtp_amd.VTP adds the SSL engines) -- runs before the compute copies are allocated"""
 
     def _param_version(self) -> int:
         return sum(p._version for p in self.parameters())
@@ -292,7 +296,7 @@ class VTPModel(nn.Module):
             wb = self.trunk.feature_bottleneck.weight
             patch_t = self._trunk.latents(out_f32=True).view(B, hw, -1).clone()
             cls_b = torch.empty(B, wb.shape[0], dtype=torch.float32, device=img.device)
-            ops.gemm_nt(self._trunk._ctx[5], self._trunk.bott.w, cls_b, M=B, N=wb.shape[0], K=wb.shape[1],
+            ops.gemm_nt(self._trunk.ctx()[5], self._trunk.bott.w, cls_b, M=B, N=wb.shape[0], K=wb.shape[1],
                         lda=(hw + 1) * wb.shape[1], epi=ops.EPI_F32)
             cls_t = cls_b
         return {"cls_token": cls_t.contiguous(), "patch_tokens": patch_t.contiguous()}

@@ -82,6 +82,10 @@ def strided_rowsum(inp, stride, out, B, D):
     _lib.check(_lib_().vtp_strided_rowsum(_p(inp), stride, _p(out), B, D, _s()), "vtp_strided_rowsum")
 
 
+def mask_rows_bwd(dx, dxb, masks, d_mask_token, B, N, D):
+    _lib.check(_lib_().vtp_mask_rows_bwd(_p(dx), _p(dxb), _p(masks), _p(d_mask_token), B, N, D, _s()), "vtp_mask_rows_bwd")
+
+
 def cast_f32_bf16(inp, out, n):
     _lib.check(_lib_().vtp_cast_f32_bf16(_p(inp), _p(out), n, _s()), "vtp_cast_f32_bf16")
 
@@ -173,3 +177,36 @@ def clip_loss(img_l, txt_l, img_all, txt_all, logit_scale, Bl, Bg, D, label_offs
     _lib.check(_lib_().vtp_clip_loss(_p(img_l), _p(txt_l), _p(img_all), _p(txt_all), _p(logit_scale), Bl, Bg, D, label_offset,
                                      _p(loss_sum), _p(d_img_l), _p(d_txt_l), _p(d_img_all), _p(d_txt_all), _p(d_logit_scale),
                                      _p(scratch), _s()), "vtp_clip_loss")
+
+
+def gather_token_rows(src, idx, dst, T, D):
+    _lib.check(_lib_().vtp_gather_token_rows(_p(src), _p(idx), _p(dst), T, D, _s()), "vtp_gather_token_rows")
+
+
+def scatter_token_rows(d_dst, idx, d_src, T, D):
+    _lib.check(_lib_().vtp_scatter_token_rows(_p(d_dst), _p(idx), _p(d_src), T, D, _s()), "vtp_scatter_token_rows")
+
+
+def weight_norm_prep(v, g, weff, weffT, inv_norm, K, C):
+    _lib.check(_lib_().vtp_weight_norm_prep(_p(v), _p(g), _p(weff), _p(weffT), _p(inv_norm), K, C, _s()), "vtp_weight_norm_prep")
+
+
+def weight_norm_bwd(dW, v, g, inv_norm, dv, dg, K, C):
+    _lib.check(_lib_().vtp_weight_norm_bwd(_p(dW), _p(v), _p(g), _p(inv_norm), _p(dv), _p(dg), K, C, _s()), "vtp_weight_norm_bwd")
+
+
+def softmax_center(logits, center, inv_temp, probs, T, K):
+    _lib.check(_lib_().vtp_softmax_center(_p(logits), _p(center), inv_temp, _p(probs), T, K, _s()), "vtp_softmax_center")
+
+
+def dino_ce(s_logits, t_probs, t0, t1, w, inv_temp, loss_sum, d_logits, T, K):
+    _lib.check(_lib_().vtp_dino_ce(_p(s_logits), _p(t_probs), _p(t0), _p(t1), _p(w), inv_temp, _p(loss_sum), _p(d_logits), T, K,
+                                   _s()), "vtp_dino_ce")
+
+
+def center_ema(center, col_sum, inv_count, momentum, K, count=None):
+    _lib.check(_lib_().vtp_center_ema(_p(center), _p(col_sum), inv_count, _p(count), momentum, K, _s()), "vtp_center_ema")
+
+
+def ema_dev(t, s, n, momentum_dev):
+    _lib.check(_lib_().vtp_ema_dev(_p(t), _p(s), n, _p(momentum_dev), _s()), "vtp_ema_dev")

@@ -90,7 +90,8 @@ class VTPTrainer:
 
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
                  group=None, bucket_blocks: int = 3, use_graphs: bool = False, clip_weight: float = 1.0,
-                 rec_weight: float = 1.0):
+                 rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
+                 teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994):
         self.model = model
         self.store = model._engine()
         self.trunk, self.decoder = model._trunk, model._decoder
@@ -99,9 +100,22 @@ class VTPTrainer:
             raise RuntimeError("VTPTrainer needs train_reconstruction=True")
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.clip_weight, self.rec_weight = clip_weight, rec_weight
+        self.dino_weight, self.ibot_weight = dino_weight, ibot_weight
+        self.student_temp, self.teacher_temp = student_temp, teacher_temp
+        self.center_momentum, self.teacher_momentum = center_momentum, teacher_momentum
+        self.ssl_head = getattr(model, "_head", None)  # vtp_amd.VTP only
         st = self.store
         self.ranges_rec = param_ranges(st.offsets, ("trunk.", "pixel_decoder."))
         self.ranges_all = param_ranges(st.offsets, ("trunk.", "pixel_decoder.") + CLIP_PREFIXES)
+        self.ranges_ssl = param_ranges(st.offsets, ("dino_head.",))
+        if self.ssl_head is not None:
+            K = self.ssl_head.K
+            self.center_dino = torch.zeros(K, dtype=F32, device=st.device)
+            self.center_ibot = torch.zeros(K, dtype=F32, device=st.device)
+            self.center_stats = torch.zeros(2 * K + 8, dtype=F32, device=st.device)  # [sum_dino | sum_ibot | n_masked, pad]
+            self.ssl_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
+            self.momentum_dev = torch.zeros(4, dtype=F32, device=st.device)
+        self._ssl_static = {}
         self.m = torch.zeros_like(st.flat_p)
         self.v = torch.zeros_like(st.flat_p)
         self.step_no = 0
@@ -130,7 +144,7 @@ class VTPTrainer:
                 "trunk_head": rng("trunk.cls_token", "trunk.mask_token", "trunk.patch_embed."),
                 "text_tail": rng("ln_final.", "text_projection"),
                 "text_head": rng("token_embedding.", "positional_embedding"),
-                "clip_head": rng("visual_proj.", "logit_scale")}
+                "clip_head": rng("visual_proj.", "logit_scale"), "dino_head": rng("dino_head.")}
         towers = [("dec", "pixel_decoder.blocks.", self.decoder.depth), ("trunk", "trunk.blocks.", self.trunk.depth)]
         if self.text is not None:
             towers.append(("text", "text_transformer.resblocks.", self.text.depth))
@@ -167,7 +181,66 @@ class VTPTrainer:
             result = stop.value
         return result
 
-    def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor]):
+    def _ssl_gen(self, P):
+        """SSL leg of the step (teacher forward, student global+local forward, DINO + iBOT loss, head and trunk backward).
+        The trunk gradients it produces are completed by the rec/clip pass that follows, so only the DINO-head bucket is
+        announced here."""
+        from .vtp import ssl_forward
+        model, st, head = self.model, self.store, self.ssl_head
+        dist = self.bucketer.dist
+        K, D = head.K, self.trunk.D
+        out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True)
+        Tt, Ts, Tm, B2, nl = out["Tt"], out["Ts"], out["Tm"], out["B2"], out["nl"]
+        n_masked = P["plan"]["n_masked"]
+        ws = out["ws"]
+        t_logits, s_logits = out["teacher_logits"], out["student_logits"]
+        probs = ws.get("probs", (Tt, K), BF)
+        ops.softmax_center(t_logits, self.center_dino, 1.0 / self.teacher_temp, probs, B2, K)
+        ops.softmax_center(t_logits[B2:], self.center_ibot, 1.0 / self.teacher_temp, probs[B2:], Tm, K)
+        # centre statistics of this batch (teacher outputs), summed over ranks, then EMA
+        stats = self.center_stats
+        stats.zero_()
+        ops.colsum_bf16(t_logits, K, stats, B2, K)
+        if n_masked > 0:
+            ops.colsum_bf16(t_logits[B2:], K, stats[K:], n_masked, K)
+        stats[2 * K:2 * K + 1].fill_(float(n_masked))
+        if self.world > 1:
+            yield lambda: dist.all_reduce(stats, group=self.group)
+        ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
+        ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
+        d_logits = ws.get("d_logits", (Ts, K), BF)
+        ops.dino_ce(s_logits, probs, P["dev"]["t0"], P["dev"]["t1"], P["dev"]["w"], 1.0 / self.student_temp, self.ssl_loss_sum,
+                    d_logits, Ts, K)
+        dX = head.backward(d_logits, out["head_ctx"])
+        yield ["dino_head"]
+        d_l = self.trunk.d_xnf_buffer(out["ctx_l"])
+        d_g = self.trunk.d_xnf_buffer(out["ctx_g"])
+        d_l.zero_()
+        d_g.zero_()
+        ops.scatter_token_rows(dX, P["dev"]["student_local_src"], d_l, nl, D)
+        ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_g, Ts - nl, D)
+        for _ in self.trunk.backward(None, ctx=out["ctx_l"]):
+            pass
+        for _ in self.trunk.backward(None, ctx=out["ctx_g"]):
+            pass
+
+    def prepare_ssl(self, global_crops: torch.Tensor, local_crops: torch.Tensor, masks) -> dict:
+        """Host-side preparation of one SSL batch (index plan + device copies); call outside the timed / captured region.
+        global_crops f32 [2B,3,R,R] (view-major), local_crops f32 [n_local*B,3,r,r], masks bool [2B, (R/16)^2]."""
+        from .ssl_engine import build_ssl_indices
+        from .vtp import plan_to_device
+        import numpy as np
+        B = global_crops.shape[0] // 2
+        hw = (global_crops.shape[-2] // 16) * (global_crops.shape[-1] // 16)
+        hw_l = (local_crops.shape[-2] // 16) * (local_crops.shape[-1] // 16)
+        n_local = local_crops.shape[0] // B
+        m = masks.detach().cpu().numpy().astype(bool) if torch.is_tensor(masks) else np.asarray(masks, bool)
+        plan = build_ssl_indices(m, B, hw, n_local, hw_l, self.dino_weight, self.ibot_weight)
+        dev = self.store.device
+        return dict(**{"global": global_crops, "local": local_crops}, masks=torch.as_tensor(m.astype(np.uint8), device=dev),
+                    plan=plan, dev=plan_to_device(plan, dev))
+
+    def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
         st = self.store
         dist = self.bucketer.dist
         B, _, H, W = images.shape
@@ -176,6 +249,9 @@ class VTPTrainer:
         st.zero_grad()
         self.loss_sum.zero_()
         self.clip_loss_sum.zero_()
+        if ssl is not None:
+            self.ssl_loss_sum.zero_()
+            yield from self._ssl_gen(ssl)
         xnf = self.trunk.forward(images, train=True)
         lat = self.trunk.latents()
         t = self.decoder.forward(lat, B, h, w, train=True)
@@ -236,10 +312,16 @@ class VTPTrainer:
         yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
         yield ["trunk_head", "FINAL"]
         # ---- optimizer (after every bucket has been reduced)
-        for lo, hi in (self.ranges_all if text is not None else self.ranges_rec):
+        ranges = list(self.ranges_all if text is not None else self.ranges_rec) + (self.ranges_ssl if ssl is not None else [])
+        for lo, hi in merge_ranges(ranges):
             ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
+        if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
+            from .vtp import _range
+            for t_pref, s_pref in (("teacher_trunk.", "trunk."), ("teacher_dino_head.", "dino_head.")):
+                (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
+                ops.ema_dev(st.flat_p[tlo:thi], st.flat_p[slo:shi], thi - tlo, self.momentum_dev)
         st.prep()
 
     # feature exchange: RCCL all-gather / reduce-scatter; on backends without them (gloo, used by the single-GPU
@@ -274,6 +356,8 @@ class VTPTrainer:
                 1.0 / self.world]
         self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
         self.hyper.copy_(self._hyper_host, non_blocking=True)
+        if self.ssl_head is not None:
+            self.momentum_dev.fill_(float(self.teacher_momentum))
 
     def _handle(self, ev):
         if callable(ev):
@@ -284,17 +368,21 @@ class VTPTrainer:
         if final:
             self.bucketer.wait()  # the generator's next (last) leg is the optimizer
 
-    def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None):
-        """One optimizer step.  images: f32 [B,3,H,W]; text: int64 [B, context_length] or None (rec only).
-        Returns (rec_loss, clip_loss) as device scalar tensors (local to this rank; no host sync)."""
+    def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None, ssl: Optional[dict] = None):
+        """One optimizer step.  images: f32 [B,3,H,W]; text: int64 [B, context_length] or None; ssl: prepare_ssl(...)
+        output or None.  Objectives: rec (always) + clip (if text) + DINO/iBOT (if ssl; model must be vtp_amd.VTP).
+        Returns (rec_loss, clip_loss) as device scalar tensors (local to this rank; no host sync); the SSL loss is in
+        self.ssl_loss_sum."""
+        if ssl is not None and self.ssl_head is None:
+            raise RuntimeError("SSL needs a vtp_amd.VTP model (DINO head + EMA teacher)")
         if text is not None and self.text is None:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
         B, _, H, W = images.shape
         self._set_hyper()
         if self.use_graphs:
-            self._step_graphs(images, text)
+            self._step_graphs(images, text, ssl)
         else:
-            for ev in self._step_gen(images, text):
+            for ev in self._step_gen(images, text, ssl):
                 self._handle(ev)
         self.model._pver = self.model._param_version()
         return self.loss_sum / float(B * 3 * H * W), self.clip_loss_sum
@@ -303,20 +391,30 @@ class VTPTrainer:
         return self.step(images, None)[0]
 
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
-    def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor]):
-        key = (tuple(images.shape), None if text is None else tuple(text.shape))
+    def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
+        skey = None
+        if ssl is not None:
+            pl = ssl["plan"]
+            skey = (tuple(ssl["global"].shape), tuple(ssl["local"].shape), pl["Ts"], pl["n_masked"])
+        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey)
         plan = self._graphs.get(key)
         if plan is None:
             st = self.store
             static_img = images.clone()
             static_txt = None if text is None else text.clone()
+            static_ssl = None
+            if ssl is not None:  # static copies of every per-step SSL input (crops, masks, index tensors)
+                static_ssl = dict(plan=ssl["plan"], masks=ssl["masks"].clone(), dev={k: v.clone() for k, v in ssl["dev"].items()})
+                static_ssl["global"], static_ssl["local"] = ssl["global"].clone(), ssl["local"].clone()
             snap = (st.flat_p.clone(), self.m.clone(), self.v.clone())
+            if ssl is not None:
+                snap = snap + (self.center_dino.clone(), self.center_ibot.clone())
             # warm-up in eager mode on a side stream (allocates every workspace buffer, sets kernel attributes); the
             # collectives run for real so that all ranks stay in lock-step
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for ev in self._step_gen(static_img, static_txt):
+                for ev in self._step_gen(static_img, static_txt, static_ssl):
                     self._handle(ev)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
@@ -324,11 +422,14 @@ class VTPTrainer:
             st.flat_p.copy_(snap[0])
             self.m.copy_(snap[1])
             self.v.copy_(snap[2])
+            if ssl is not None:
+                self.center_dino.copy_(snap[3])
+                self.center_ibot.copy_(snap[4])
             st.prep()
             del snap
             segs = []
             pool = torch.cuda.graph_pool_handle()
-            gen = self._step_gen(static_img, static_txt)
+            gen = self._step_gen(static_img, static_txt, static_ssl)
             done = False
             while not done:
                 g = torch.cuda.CUDAGraph()
@@ -339,12 +440,18 @@ class VTPTrainer:
                     except StopIteration:
                         done = True
                 segs.append((g, ev))
-            plan = (static_img, static_txt, segs)
+            plan = (static_img, static_txt, static_ssl, segs)
             self._graphs[key] = plan
-        static_img, static_txt, segs = plan
+        static_img, static_txt, static_ssl, segs = plan
         static_img.copy_(images)
         if text is not None:
             static_txt.copy_(text)
+        if ssl is not None:
+            static_ssl["global"].copy_(ssl["global"])
+            static_ssl["local"].copy_(ssl["local"])
+            static_ssl["masks"].copy_(ssl["masks"])
+            for k, v in ssl["dev"].items():
+                static_ssl["dev"][k].copy_(v)
         for g, ev in segs:
             g.replay()
             if ev is not None:

@@ -1,0 +1,158 @@
+"""VTP -- the *training* meta-architecture (reference: vtp/models/vtp.py:88-552) on the MI355X kernels.
+
+`VTP` = `VTPModel` (trunk, pixel decoder, text tower, CLIP projection; same checkpoint keys as the HF class) plus the
+self-supervised branch of the legacy class, under the legacy attribute names:
+    dino_head.{mlp.0,mlp.2,mlp.4}.{weight,bias}, dino_head.last_layer.{weight_g,weight_v}     (dino_head.py:7-89)
+    teacher_trunk.*  (frozen EMA copy of trunk.*),  teacher_dino_head.*                      (vtp.py:253-268)
+and its methods `update_teacher(momentum)` (vtp.py:388-401), `get_ssl_params()` (vtp.py:403-407) and
+`forward_ssl_learning(**ssl_dict)` (vtp.py:365-385, output dict keys of vtp.py:446-448,479-484).
+The reference configures this class from an OmegaConf tree; here the same knobs are constructor arguments."""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .config import VTPConfig
+from .engine import BF, F32, TrunkEngine
+from .model import VTPModel, _holder, _param
+from .ssl_engine import DinoHeadEngine, build_ssl_indices
+
+I32 = torch.int32
+
+
+def _dino_head_tree(in_dim: int, hidden: int, bott: int, K: int) -> nn.Module:
+    h = _holder()
+    h.mlp = nn.ModuleList([_holder() for _ in range(5)])  # indices 0, 2, 4 carry parameters (1, 3 are GELUs)
+    for i, (o, k) in zip((0, 2, 4), ((hidden, in_dim), (hidden, hidden), (bott, hidden))):
+        h.mlp[i].weight = _param(o, k)
+        h.mlp[i].bias = _param(o)
+    h.last_layer = _holder()
+    h.last_layer.weight_g = _param(K, 1)
+    h.last_layer.weight_v = _param(K, bott)
+    return h
+
+
+class VTP(VTPModel):
+    def __init__(self, config: VTPConfig, dino_out_dim: int = 65536, dino_hidden_dim: int = 2048,
+                 dino_bottleneck_dim: int = 256, dino_nlayers: int = 3):
+        super().__init__(config)
+        if dino_nlayers != 3:
+            raise ValueError("only the 3-layer DINO head MLP is implemented")
+        if not config.vision_bottleneck_ae_only:
+            raise NotImplementedError("the DINO head reads the un-bottlenecked trunk features (bottleneck_ae_only=True)")
+        D = config.vision_embed_dim
+        self.dino_cfg = dict(in_dim=D, hidden=dino_hidden_dim, bott=dino_bottleneck_dim, K=dino_out_dim)
+        self.dino_head = _dino_head_tree(D, dino_hidden_dim, dino_bottleneck_dim, dino_out_dim)
+        with torch.no_grad():
+            for i in (0, 2, 4):
+                nn.init.trunc_normal_(self.dino_head.mlp[i].weight, std=0.02)
+                self.dino_head.mlp[i].bias.zero_()
+            nn.init.trunc_normal_(self.dino_head.last_layer.weight_v, std=0.02)
+            self.dino_head.last_layer.weight_g.fill_(1.0)
+        self.teacher_trunk = copy.deepcopy(self.trunk)
+        self.teacher_dino_head = copy.deepcopy(self.dino_head)
+        for p in list(self.teacher_trunk.parameters()) + list(self.teacher_dino_head.parameters()):
+            p.requires_grad = False
+        self.enable_teacher = True
+
+    # ------------------------------------------------------------------------------------------------ engine
+    def _build_extra_engines(self, st):
+        c = self.dino_cfg
+        self._t_trunk = TrunkEngine(st, self.config, self.teacher_trunk.rope_embed.periods, prefix="teacher_trunk.")
+        self._head = DinoHeadEngine(st, "dino_head.", c["in_dim"], c["hidden"], c["bott"], c["K"])
+        self._t_head = DinoHeadEngine(st, "teacher_dino_head.", c["in_dim"], c["hidden"], c["bott"], c["K"])
+
+    # ------------------------------------------------------------------------------------------------ legacy API
+    def get_ssl_params(self):
+        return list(self.dino_head.parameters()) if self.enable_teacher else []
+
+    @torch.no_grad()
+    def update_teacher(self, momentum: float):
+        """teacher = m * teacher + (1 - m) * student over trunk and dino_head parameters (vtp.py:388-401): two fused
+        launches over contiguous ranges of the flat parameter buffer."""
+        st = self._engine()
+        for t_pref, s_pref in (("teacher_trunk.", "trunk."), ("teacher_dino_head.", "dino_head.")):
+            (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
+            assert thi - tlo == shi - slo
+            ops.ema(st.flat_p[tlo:thi], st.flat_p[slo:shi], thi - tlo, momentum)
+        st.prep()
+        self._pver = self._param_version()
+
+    @torch.no_grad()
+    def forward_ssl_learning(self, global_crops, n_global_crops, mask_indices_list, n_masked_patches, upperbound,
+                             local_crops, masks):
+        """Inference-mode SSL forward with the legacy signature/outputs (vtp.py:365-385): returns
+        (teacher_outputs, student_outputs) with the reference's dict keys; logits are f32 copies of the bf16 kernels'
+        outputs.  (Training goes through VTPTrainer.step(..., ssl=...).)"""
+        if n_global_crops != 2:
+            raise NotImplementedError("n_global_crops must be 2")
+        self._fresh()
+        B2 = global_crops.shape[0]
+        B = B2 // 2
+        hw = (global_crops.shape[-2] // 16) * (global_crops.shape[-1] // 16)
+        hw_l = (local_crops.shape[-2] // 16) * (local_crops.shape[-1] // 16)
+        n_local = local_crops.shape[0] // B
+        plan = build_ssl_indices(masks.detach().cpu().numpy().astype(bool), B, hw, n_local, hw_l, 1.0, 1.0, pad_to=8)
+        assert plan["n_masked"] == int(n_masked_patches) <= int(upperbound)
+        out = ssl_forward(self, self._img(global_crops), self._img(local_crops), masks.to(self._store.device), plan, train=False)
+        nm, nl = plan["n_masked"], n_local * B
+        tl, sl = out["teacher_logits"].float(), out["student_logits"].float()
+        teacher_outputs = {"teacher_cls_tokens_after_head": tl[:B2].clone(), "n_masked_patches": n_masked_patches,
+                           "masked_teacher_patch_tokens_after_head": tl[B2:B2 + nm].clone()}
+        student_outputs = {"student_local_cls_tokens_after_head": sl[:nl].clone(),
+                           "student_global_cls_tokens_after_head": sl[nl:nl + B2].clone(),
+                           "student_global_cls_tokens": out["student_global_cls"].float().clone(),
+                           "student_global_masked_patch_tokens_after_head": sl[nl + B2:nl + B2 + nm].clone()}
+        return teacher_outputs, student_outputs
+
+
+def _range(st, prefix):
+    offs = [(o, o + (k + 3) // 4 * 4) for n, (o, k) in st.offsets.items() if n.startswith(prefix)]
+    lo, hi = min(o for o, _ in offs), max(h for _, h in offs)
+    assert sum(h - o for o, h in offs) == hi - lo, f"{prefix} is not contiguous in the flat buffer"
+    return lo, hi
+
+
+def plan_to_device(plan, device):
+    """int32 / f32 index tensors of one SSL batch on the device (done outside any graph capture)."""
+    d = {k: torch.as_tensor(plan[k], device=device) for k in ("teacher_src", "student_local_src", "student_global_src", "t0", "t1")}
+    d["w"] = torch.as_tensor(plan["w"], device=device)
+    return d
+
+
+def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_plan=None, train: bool = False):
+    """Teacher + student forward of one SSL batch (vtp.py:410-484).  Returns a dict with the head logits and the
+    contexts the backward needs.  masks_u8: uint8 [2B, hw] on the device; plan: build_ssl_indices() output."""
+    st = model._store
+    B2 = global_crops.shape[0]
+    hw = (global_crops.shape[-2] // 16) * (global_crops.shape[-1] // 16)
+    N = hw + 1
+    D = model.config.vision_embed_dim
+    idx = plan_to_device(plan, st.device) if dev_plan is None else dev_plan
+    Tm, Ts = plan["Tm"], plan["Ts"]
+    Tt = B2 + Tm
+    if masks_u8.dtype != torch.uint8:
+        masks_u8 = masks_u8.to(torch.uint8).contiguous()
+    # ---- teacher (EMA weights, clean input, no gradient): vtp.py:410-450
+    xnf_t = model._t_trunk.forward(global_crops, train=False, tag="teacher")
+    ws = model._head.workspace(Ts, "ssl_io")
+    Xt = ws.get("Xt", (Tt, D), BF)
+    ops.gather_token_rows(xnf_t, idx["teacher_src"], Xt, Tt, D)
+    t_logits, _ = model._t_head.forward(Xt, Tt, tag="teacher")
+    # ---- student: masked global crops + local crops through the SAME trunk weights (vtp.py:452-484)
+    xnf_g = model._trunk.forward(global_crops, train=train, masks=masks_u8, tag="ssl_g")
+    ctx_g = model._trunk.ctx()
+    xnf_l = model._trunk.forward(local_crops, train=train, tag="ssl_l")
+    ctx_l = model._trunk.ctx()
+    nl = int(plan["student_local_src"].shape[0])
+    Xs = ws.get("Xs", (Ts, D), BF)
+    ops.gather_token_rows(xnf_l, idx["student_local_src"], Xs, nl, D)
+    ops.gather_token_rows(xnf_g, idx["student_global_src"], Xs[nl:], Ts - nl, D)
+    s_logits, head_ctx = model._head.forward(Xs, Ts, tag="student")
+    return dict(teacher_logits=t_logits, student_logits=s_logits, head_ctx=head_ctx, ctx_g=ctx_g, ctx_l=ctx_l, idx=idx,
+                Xs=Xs, student_global_cls=Xs[nl:nl + B2], Tt=Tt, Ts=Ts, Tm=Tm, nl=nl, B2=B2, N=N, ws=ws)
