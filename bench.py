@@ -36,7 +36,8 @@ _SMALL = dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_em
               text_num_heads=6, decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6)
 WORKLOADS = {
     # name: (config kwargs, per-GPU batch, resolution, objectives)
-    "vtp_base_rec_clip": (dict(), 32, 256, ("rec", "clip")),   # BASELINE config 3 minus the SSL head (not built yet)
+    "vtp_base_full": (dict(), 32, 256, ("rec", "clip", "ssl")),  # BASELINE config 3: contrastive + SSL + recon
+    "vtp_base_rec_clip": (dict(), 32, 256, ("rec", "clip")),
     "vtp_base_rec": (dict(), 32, 256, ("rec",)),
     "vtp_small_rec": (_SMALL, 64, 256, ("rec",)),               # BASELINE config 2
 }
@@ -53,6 +54,22 @@ def synthetic_captions(B, T, vocab, device, seed):
     ids = torch.where(ar < ln[:, None], ids, torch.zeros_like(ids))
     ids[torch.arange(B), ln] = vocab - 1
     return ids.to(device)
+
+
+def synthetic_ssl(B, res, device, seed, local_res=96, n_local=8):
+    """2 global crops at res^2 + 8 local crops at 96^2 per image (DINOv2 convention, unpinned); iBOT masks:
+    half of the global crops masked at a ratio ~ U(0.1, 0.5)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    hw = (res // 16) ** 2
+    gc = torch.randn(2 * B, 3, res, res, device=device, generator=g)
+    lc = torch.randn(n_local * B, 3, local_res, local_res, device=device, generator=g)
+    gh = torch.Generator().manual_seed(seed)
+    masks = torch.zeros(2 * B, hw, dtype=torch.bool)
+    for i in range(2 * B):
+        if torch.rand(1, generator=gh).item() < 0.5:
+            ratio = 0.1 + 0.4 * torch.rand(1, generator=gh).item()
+            masks[i, torch.randperm(hw, generator=gh)[:int(ratio * hw)]] = True
+    return gc, lc, masks
 
 
 def text_fwd_gflop(D, L, T):
@@ -112,11 +129,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vtp_base_rec_clip", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
+    ap.add_argument("--prototypes", type=int, default=65536, help="DINO head out_dim K (DINOv2 default 65536; unpinned)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,15 +151,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from vtp_amd import VTPConfig, VTPModel, VTPTrainer, ops
+    from vtp_amd import VTP, VTPConfig, VTPModel, VTPTrainer, ops
     cfg_kw, B, res, objectives = WORKLOADS[args.workload]
-    clip = "clip" in objectives
+    clip, do_ssl = "clip" in objectives, "ssl" in objectives
     B = args.batch or B
     torch.manual_seed(0)
-    model = VTPModel(VTPConfig(**cfg_kw)).to(dev)
+    model = (VTP(VTPConfig(**cfg_kw), dino_out_dim=args.prototypes) if do_ssl else VTPModel(VTPConfig(**cfg_kw))).to(dev)
     trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs)
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
+    ssl = None
+    if do_ssl:
+        gc, lc, masks = synthetic_ssl(B, res, dev, 777 + rank)
+        ssl = trainer.prepare_ssl(gc, lc, masks)
 
     def sync():
         if world > 1:
@@ -149,11 +171,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(img, txt)
+        trainer.step(img, txt, ssl)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, closs = trainer.step(img, txt)
+        loss, closs = trainer.step(img, txt, ssl)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -182,7 +204,7 @@ def main():
         ops.gemm_nt = timed_gemm
         trainer.use_graphs = False  # the instrumented step launches eagerly (events cannot sit inside a replayed graph)
         try:
-            trainer.step(img, txt)
+            trainer.step(img, txt, ssl)
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt = orig
@@ -205,6 +227,21 @@ def main():
     tflop = text_fwd_gflop(c.text_embed_dim, c.text_depth, c.text_context_length) if clip else 0.0
     gflop_img = 3.0 * (enc + dec + tflop)            # executed: one shared trunk pass serves rec and clip
     gflop_ref = 3.0 * (enc + dec) + (3.0 * (enc + tflop) if clip else 0.0)  # BASELINE.md accounting (separate passes)
+    ssl_info = None
+    if do_ssl:
+        hw_l = (96 // 16) ** 2
+        loc = vit_fwd_gflop(c.vision_embed_dim, swiglu_hidden(c.vision_embed_dim), c.vision_depth, hw_l + 1, hw_l, True) \
+            - 2 * (hw_l + 1) * c.vision_embed_dim * 64 / 1e9
+        enc_nb = enc - 2 * (hw + 1) * c.vision_embed_dim * 64 / 1e9   # SSL passes do not use the bottleneck
+        ssl_trunk = 3.0 * (2 * enc_nb + 8 * loc) + 2 * enc_nb          # student fwd+bwd (2 global + 8 local) + teacher fwd
+        dh = model.dino_cfg
+        tok_flop = 2.0 * (dh["in_dim"] * dh["hidden"] + dh["hidden"] ** 2 + dh["hidden"] * dh["bott"] + dh["bott"] * dh["K"])
+        pl = ssl["plan"]
+        head = (3.0 * pl["Ts"] + (2 * B + pl["Tm"])) * tok_flop / 1e9 / B   # student fwd+bwd + teacher fwd, per image
+        gflop_img += ssl_trunk + head
+        gflop_ref += ssl_trunk + head
+        ssl_info = {"prototypes": dh["K"], "masked_tokens": pl["n_masked"], "student_head_rows": pl["Ts"],
+                    "global_crops": 2, "local_crops": 8, "local_res": 96, "ssl_loss": round(float(trainer.ssl_loss_sum), 4)}
     ips = world * B * args.steps / elapsed
     out = {
         "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload.startswith("vtp_base")
@@ -212,15 +249,16 @@ def main():
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: full optimizer step (fwd + {'L1 recon + CLIP contrastive' if clip else 'L1 recon'} "
-                               f"loss + bwd + grad all-reduce{' + feature all-gather/reduce-scatter' if clip else ''} + AdamW) of VTPModel "
-                               f"trunk + pixel_decoder{' + text tower' if clip else ''}, {B} img/GPU @ {res}x{res}"
-                               f"{', 77-token synthetic captions' if clip else ''}, random-init weights; the SSL (DINO/iBOT) "
-                               "head of BASELINE config 3 is not built yet",
+        "config": {"workload": f"{args.workload}: full optimizer step (fwd + {' + '.join(objectives)} losses + bwd + bucketed grad "
+                               f"all-reduce{' + feature all-gather/reduce-scatter' if clip else ''} + fused AdamW"
+                               f"{' + EMA teacher' if do_ssl else ''}) of trunk + pixel_decoder{' + text tower' if clip else ''}"
+                               f"{' + DINO head + EMA teacher trunk (2 global + 8 local-96 crops/img, iBOT masks)' if do_ssl else ''}, "
+                               f"{B} img/GPU @ {res}x{res}{', 77-token synthetic captions' if clip else ''}, random-init weights; "
+                               "rec and clip share one trunk pass (identical activations at drop rate 0); LPIPS term not included",
                    "launch": "eager" if args.no_graphs else "hipGraph segments", "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
-        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5),
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info,
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
@@ -228,6 +266,8 @@ def main():
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res, clip)
+            if do_ssl:
+                out["cpu_baseline"]["note"] = "CPU sample covers the rec+clip objectives only (K=65536-prototype SSL on CPU exceeds the time bound)"
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
