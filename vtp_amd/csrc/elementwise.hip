@@ -390,21 +390,31 @@ __global__ __launch_bounds__(256) void strided_rowsum_kernel(const float* __rest
 }
 
 // backward of the mask-token substitution (vision_transformer.py:195): rows whose patch embedding was replaced by
-// mask_token send their gradient to mask_token and nothing to the patch embedding.  thread = one feature column.
+// mask_token send their gradient to mask_token and nothing to the patch embedding.  One workgroup per 16 token rows,
+// thread = feature columns; per-block partial sums -> one atomic per column per block.
 __global__ __launch_bounds__(256) void mask_rows_bwd_kernel(const float* __restrict__ dx, bf16* __restrict__ dxb,
                                                             const unsigned char* __restrict__ masks, float* __restrict__ d_mask,
                                                             int B, int N, int D) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int n = 1; n < N; ++n)
-      if (masks[(long)b * (N - 1) + (n - 1)]) {
-        const long o = ((long)b * N + n) * D + d;
+  const long rows = (long)B * N;
+  const long r0 = (long)blockIdx.x * 16;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    bool any = false;
+    for (int i = 0; i < 16; ++i) {
+      const long r = r0 + i;
+      if (r >= rows) break;
+      const int n = (int)(r % N);
+      if (n == 0) continue;
+      const long b = r / N;
+      if (masks[b * (N - 1) + (n - 1)]) {
+        const long o = r * D + d;
         s += dx[o];
         dxb[o] = (bf16)0.f;
+        any = true;
       }
-  d_mask[d] += s;
+    }
+    if (any) unsafeAtomicAdd(d_mask + d, s);
+  }
 }
 
 static inline int grid_for(long items, int cap = 4096) {
@@ -470,7 +480,7 @@ extern "C" int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_sw
 extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,
                                  int D, void* stream) {
   VTP_REQUIRE(dx && dx_bf16 && masks && d_mask_token && B > 0 && N > 1 && D > 0, "vtp_mask_rows_bwd: bad argument");
-  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, dx, (bf16*)dx_bf16, masks,
+  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv((long)B * N, 16)), dim3(256), 0, (hipStream_t)stream, dx, (bf16*)dx_bf16, masks,
                      d_mask_token, B, N, D);
   return check_launch("mask_rows_bwd");
 }

@@ -74,10 +74,11 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
 }
 
 template <int KIND, int NC>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ stats,
                                                        const float* __restrict__ dres, float* __restrict__ dx,
                                                        bf16* __restrict__ dxb, float* __restrict__ dw, float* __restrict__ db, int M, int D) {
+  constexpr int R = NC <= 3 ? 2 : 1;  // rows in flight per wave: the x / dy loads of all R rows are issued before the first reduction
   const int lane = threadIdx.x & 63;
   const int wv_id = threadIdx.x >> 6;
   f32x4 wreg[NC], dwacc[NC], dbacc[NC];
@@ -88,45 +89,59 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
     dwacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dbacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 4 + wv_id; row < M; row += gridDim.x * 4) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    const float* xr = x + (size_t)row * D;
-    const bf16* gr = dy + (size_t)row * D;
-    f32x4 xh[NC], g[NC];
-    float s1 = 0.f, s2 = 0.f;
+  for (int row0 = (blockIdx.x * 4 + wv_id) * R; row0 < M; row0 += gridDim.x * 4 * R) {
+    f32x4 xv[R][NC];
+    bf16x4 gy[R][NC];
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      if (col < D) {
-        f32x4 xv = *(const f32x4*)(xr + col);
-        f32x4 gy = __builtin_convertvector(*(const bf16x4*)(gr + col), f32x4);
+    for (int r = 0; r < R; ++r) {
+      const int row = min(row0 + r, M - 1);
+      mean[r] = stats[2 * row];
+      rstd[r] = stats[2 * row + 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[c][e] = (xv[e] - mean) * rstd;
-          g[c][e] = gy[e] * wreg[c][e];
-          s1 += g[c][e];
-          s2 += g[c][e] * xh[c][e];
-          dwacc[c][e] += gy[e] * xh[c][e];
-          dbacc[c][e] += gy[e];
+      for (int c = 0; c < NC; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        if (col < D) {
+          xv[r][c] = *(const f32x4*)(x + (size_t)row * D + col);
+          gy[r][c] = *(const bf16x4*)(dy + (size_t)row * D + col);
         }
       }
     }
-    s2 = wave_sum(s2) / D;
-    if (KIND == 1) s1 = wave_sum(s1) / D; else s1 = 0.f;
-    float* dxr = dx + (size_t)row * D;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      if (col < D) {
-        f32x4 o;
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      if (row >= M) break;
+      f32x4 xh[NC], g[NC];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] - s1 - xh[c][e] * s2);
-        if (dres) {
-          f32x4 r = *(const f32x4*)(dres + (size_t)row * D + col);
-          o += r;
+      for (int c = 0; c < NC; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        if (col < D) {
+          f32x4 gyf = __builtin_convertvector(gy[r][c], f32x4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[c][e] = (xv[r][c][e] - mean[r]) * rstd[r];
+            g[c][e] = gyf[e] * wreg[c][e];
+            s1 += g[c][e];
+            s2 += g[c][e] * xh[c][e];
+            dwacc[c][e] += gyf[e] * xh[c][e];
+            dbacc[c][e] += gyf[e];
+          }
         }
-        *(f32x4*)(dxr + col) = o;
-        if (dxb) *(bf16x4*)(dxb + (size_t)row * D + col) = __builtin_convertvector(o, bf16x4);
+      }
+      s2 = wave_sum(s2) / D;
+      if (KIND == 1) s1 = wave_sum(s1) / D; else s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        if (col < D) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (g[c][e] - s1 - xh[c][e] * s2);
+          if (dres) o += *(const f32x4*)(dres + (size_t)row * D + col);
+          *(f32x4*)(dx + (size_t)row * D + col) = o;
+          if (dxb) *(bf16x4*)(dxb + (size_t)row * D + col) = __builtin_convertvector(o, bf16x4);
+        }
       }
     }
   }
@@ -178,7 +193,7 @@ extern "C" int vtp_norm_bwd(const void* dy, const float* x, const float* w, cons
   VTP_REQUIRE(dy && x && w && stats && dx, "vtp_norm_bwd: null pointer");
   VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
   VTP_REQUIRE(kind == 0 || kind == 1, "vtp_norm_bwd: kind must be 0 or 1");
-  int blocks = cdiv(M, 4);
+  int blocks = cdiv(M, D <= 768 ? 8 : 4);
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
   if (kind == 0)

@@ -74,7 +74,15 @@ class DinoHeadEngine:
         ops.gemm_tn(d_logits, zn_b, dWeff, M=K, N=bott, K=T, lda=K, ldb=bott, ldc=bott, epi=EPI_F32)
         ops.weight_norm_bwd(dWeff, self.v, self.g, self.inv_norm, self.gv, self.gg, K, bott)
         d_zn = ws.get("b.d_zn", (T, bott), F32)
-        ops.gemm_nt(d_logits, self.weffT, d_zn, M=T, N=bott, K=K, epi=EPI_F32)
+        # reduction over K = 65536 prototypes with only T/128 x bott/128 output tiles: split-K slabs + one reduce
+        S = ops.gemm_splits(K, max(1, min(16, K // 2048)))
+        if S == 1:
+            ops.gemm_nt(d_logits, self.weffT, d_zn, M=T, N=bott, K=K, epi=EPI_F32)
+        else:
+            slab = ws.get("b.d_zn_slab", (S * T * bott,), F32)
+            ops.gemm_nt(d_logits, self.weffT, slab, M=T, N=bott, K=K, ldc=bott, ldc2=T * bott // 4, epi=ops.EPI_F32_SLAB,
+                        splits=S)
+            ops.reduce_slabs(slab, T * bott, S, d_zn, T * bott, accumulate=False)
         dz = ws.get("b.dz", (T, bott), F32)
         ops.l2norm_bwd(d_zn, zn, inv_z, dz, T, bott)
         dz_b = ws.get("b.dz_b", (T, bott), BF)
