@@ -20,7 +20,9 @@ namespace vtp {
 
 constexpr int KT = 64;        // keys (or queries) per staged tile
 constexpr int RS = 72;        // row stride (elements) of row-major [64][64] tiles
-constexpr int TS = 68;        // row stride (elements) of transposed [64 d][64 seq] tiles
+constexpr int TS = 68;        // row stride (elements) of transposed [64 d][64 seq] tiles (legacy scatter path)
+constexpr int RT = 96;        // row stride (elements) of row-major tiles that are read with ds_read_b64_tr_b16 (4 rows x 64 B
+                              // of one half-wave land on 4 disjoint 16-dword bank ranges: 0, 48, 32, 16)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -56,6 +58,32 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long s
   }
 }
 
+// stage a [64 rows][64 d] tile row-major into up to two LDS images with different row strides (16-B writes only)
+template <int S1, int S2>
+__device__ __forceinline__ void stage_tile2(const bf16* __restrict__ base, long sn, int row0, int N, bf16* d1, bf16* d2) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * 256;
+    const int r = c >> 3, dc = (c & 7) * 8;
+    const int n = min(row0 + r, N - 1);
+    bf16x8 v = *(const bf16x8*)(base + (long)n * sn + dc);
+    if (S1 > 0) *(bf16x8*)(d1 + r * S1 + dc) = v;
+    if (S2 > 0) *(bf16x8*)(d2 + r * S2 + dc) = v;
+  }
+}
+
+// A-operand fragment of the TRANSPOSED tile, formed with the gfx950 LDS transpose read from a row-major [seq][64 d]
+// image (row stride RT): lane row d = dblk*32 + (lane&31); k-slots are seq = blk*32 + 16*ks + 4*hi + {0..3} and + 8 +
+// {0..3} -- the accumulator register order.  In each 16-lane group lane i supplies the address of row (i>>2), columns
+// 4*(i&3).., and receives column i of the 4 x 16 block.
+__device__ __forceinline__ bf16x8 frag_trr(const bf16* tile, int dblk, int blk, int ks, int lane) {
+  const int i = lane & 15, g = (lane >> 4) & 1, hi = lane >> 5;
+  const bf16* p = tile + (blk * 32 + ks * 16 + hi * 4 + (i >> 2)) * RT + dblk * 32 + g * 16 + (i & 3) * 4;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+  bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 8 * RT));
+  return cat4(lo, hi4);
+}
+
 // A-operand fragment from a row-major tile: lane row (lane&31) of 32-row block `blk`, k-step ks (16 d), 16 B
 __device__ __forceinline__ bf16x8 frag_rm(const bf16* rm, int blk, int ks, int lane) {
   return *(const bf16x8*)(rm + (blk * 32 + (lane & 31)) * RS + ks * 16 + (lane >> 5) * 8);
@@ -83,7 +111,7 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[KT * RS];
-  __shared__ __attribute__((aligned(16))) bf16 Vt[64 * TS];
+  __shared__ __attribute__((aligned(16))) bf16 Vr[KT * RT];   // V row-major, read transposed (tr16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int qw0 = blockIdx.x * 128;
@@ -110,8 +138,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const int ntiles = (kend + KT - 1) / KT;
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();
-    stage_tile<true, false>(kb_, p.sn, t * KT, p.N, Ks, nullptr);
-    stage_tile<false, true>(vb, p.sn, t * KT, p.N, nullptr, Vt);
+    stage_tile2<RS, 0>(kb_, p.sn, t * KT, p.N, Ks, nullptr);
+    stage_tile2<RT, 0>(vb, p.sn, t * KT, p.N, Vr, nullptr);
     __syncthreads();
     if (!wave_active) continue;
     const int nkb = min(2, (kend - t * KT + 31) / 32);
@@ -151,8 +179,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
       const bf16x8 pf0 = pack8(s, 0), pf1 = pack8(s, 8);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, db, kb, 0, lane), pf0, oacc[db], 0, 0, 0);
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vt, db, kb, 1, lane), pf1, oacc[db], 0, 0, 0);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Vr, db, kb, 0, lane), pf0, oacc[db], 0, 0, 0);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Vr, db, kb, 1, lane), pf1, oacc[db], 0, 0, 0);
       }
     }
   }
@@ -197,7 +225,7 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[KT * RS];
   __shared__ __attribute__((aligned(16))) bf16 Vs[KT * RS];
-  __shared__ __attribute__((aligned(16))) bf16 Ktr[64 * TS];
+  __shared__ __attribute__((aligned(16))) bf16 Kr[KT * RT];   // second row-major K image, read transposed (tr16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int qw0 = blockIdx.x * 128;
@@ -230,8 +258,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int ntiles = (kend + KT - 1) / KT;
   for (int t = 0; t < ntiles; ++t) {
     __syncthreads();
-    stage_tile<true, true>(kb_, p.sn, t * KT, p.N, Ks, Ktr);
-    stage_tile<true, false>(vb, p.sn, t * KT, p.N, Vs, nullptr);
+    stage_tile2<RS, RT>(kb_, p.sn, t * KT, p.N, Ks, Kr);
+    stage_tile2<RS, 0>(vb, p.sn, t * KT, p.N, Vs, nullptr);
     __syncthreads();
     if (!wave_active) continue;
     const int nkb = min(2, (kend - t * KT + 31) / 32);
@@ -256,8 +284,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
       const bf16x8 d0 = pack8(s, 0), d1 = pack8(s, 8);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ktr, db, kb, 0, lane), d0, dq[db], 0, 0, 0);
-        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ktr, db, kb, 1, lane), d1, dq[db], 0, 0, 0);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Kr, db, kb, 0, lane), d0, dq[db], 0, 0, 0);
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Kr, db, kb, 1, lane), d1, dq[db], 0, 0, 0);
       }
     }
   }
@@ -279,8 +307,8 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16 Qs[KT * RS];
   __shared__ __attribute__((aligned(16))) bf16 Gs[KT * RS];   // dO row-major
-  __shared__ __attribute__((aligned(16))) bf16 Qtr[64 * TS];
-  __shared__ __attribute__((aligned(16))) bf16 Gtr[64 * TS];
+  __shared__ __attribute__((aligned(16))) bf16 Qr[KT * RT];   // row-major images read transposed (tr16)
+  __shared__ __attribute__((aligned(16))) bf16 Gr[KT * RT];
   __shared__ __attribute__((aligned(16))) float lse_s[KT];
   __shared__ __attribute__((aligned(16))) float dlt_s[KT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
@@ -315,8 +343,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const long srow0 = ((long)b * p.heads + h) * p.N;
   for (int t = t0; t < ntiles; ++t) {
     __syncthreads();
-    stage_tile<true, true>(qb, p.sn, t * KT, p.N, Qs, Qtr);
-    stage_tile<true, true>(gb, p.sno, t * KT, p.N, Gs, Gtr);
+    stage_tile2<RS, RT>(qb, p.sn, t * KT, p.N, Qs, Qr);
+    stage_tile2<RS, RT>(gb, p.sno, t * KT, p.N, Gs, Gr);
     if (threadIdx.x < KT) {
       const int qn = min(t * KT + (int)threadIdx.x, p.N - 1);
       lse_s[threadIdx.x] = p.lse[srow0 + qn] * LOG2E;
@@ -354,10 +382,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
       const bf16x8 p0 = pack8(pr, 0), p1 = pack8(pr, 8), d0 = pack8(s, 0), d1 = pack8(s, 8);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gtr, db, qblk, 0, lane), p0, dv[db], 0, 0, 0);
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gtr, db, qblk, 1, lane), p1, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qtr, db, qblk, 0, lane), d0, dk[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qtr, db, qblk, 1, lane), d1, dk[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Gr, db, qblk, 0, lane), p0, dv[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Gr, db, qblk, 1, lane), p1, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Qr, db, qblk, 0, lane), d0, dk[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trr(Qr, db, qblk, 1, lane), d1, dk[db], 0, 0, 0);
       }
     }
   }
