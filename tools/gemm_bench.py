@@ -21,8 +21,8 @@ SHAPES = [  # (tag, M, N, K, epilogue)
     ("wgrad_proj", 768, 768, 8224, ops.EPI_F32_SLAB),
     ("big_4096", 4096, 4096, 4096, ops.EPI_BF16),
 ]
-CFGS = {0: "128x128 4w s2", 1: "128x128 4w s3", 6: "128x128 4w s4", 5: "128x128 8w s2", 2: "256x128 8w s2",
-        3: "256x128 8w s3", 4: "256x256 8w s2"}
+CFGS = {0: "128x128 4w s2", 16: "128x128 4w s2 PIPE", 5: "128x128 8w s2", 21: "128x128 8w s2 PIPE", 2: "256x128 8w s2",
+        18: "256x128 8w s2 PIPE", 4: "256x256 8w s2"}
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
         ref = None
         for cfg, name in CFGS.items():
             for swz in (1, 0):
-                if swz == 0 and cfg not in (0, 2):
+                if swz == 0:
                     continue
                 lib.vtp_set_gemm_tuning(cfg, swz)
                 kw = {}

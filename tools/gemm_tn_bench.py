@@ -9,7 +9,7 @@ from vtp_amd import _lib, ops
 
 SHAPES = [("wgrad_qkv", 2304, 768, 8224), ("wgrad_w12", 4096, 768, 8224), ("wgrad_proj", 768, 768, 8224),
           ("wgrad_w3", 768, 2048, 8224)]
-CFGS = {0: "128x128 4w s2", 5: "128x128 8w s2", 2: "256x128 8w s2", 3: "256x128 8w s3"}
+CFGS = {0: "128x128 4w s2", 16: "128x128 4w s2 PIPE", 5: "128x128 8w s2", 21: "128x128 8w s2 PIPE"}
 
 
 def main():

@@ -15,6 +15,7 @@
 // lane-local SwiGLU / bias.  Workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous band
 // of output rows and sweeps the weight panel (blocks b, b+8, ... run on the same XCD).
 #include "common.h"
+#include <cstdlib>
 #include "vtp_hip.h"
 
 namespace vtp {
@@ -57,7 +58,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                (weight gradients dW = dY^T X straight from the activation layouts).  The LDS image of a tile is then
 //                [64 k][BM or BN cols] as in global memory (slot index XOR 4*(k&3)), and MFMA fragments are formed with
 //                ds_read_b64_tr_b16: 16 lanes fetch a 4(k) x 16(col) block and each lane receives one column.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS>
+// PIPE = true: software-pipelined k-tile body -- the LDS-DMA pieces of the next tile are issued in four slices between
+// the MFMA groups (their issue cost hides behind the matrix pipe) and the fragments of k-step ks+1 are read while the
+// MFMAs of k-step ks execute.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS, bool PIPE>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int BK = 64;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -137,12 +141,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
     }
   }
 
-  auto stage = [&](int buf, int kt) {
+  // q < 0: issue every piece of the tile; q in 0..3: only the pieces j with j % 4 == q (A pieces are j = 0..PA-1)
+  auto stage_part = [&](int buf, int kt, int q) {
     char* abase = smem + buf * STAGE_BYTES;
     char* bbase = abase + A_BYTES;
     const int krem = kend - kbeg - kt * BK;  // valid k elements left in this tile (>0)
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
+      if (q >= 0 && (i & 3) != q) continue;
       const char* s;
       if constexpr (!TRANS) {
         s = (a_kc[i] < krem) ? a_src[i] + (size_t)kt * (BK * 2) : zsrc;
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
+      if (q >= 0 && ((i + PA) & 3) != q) continue;
       const char* s;
       if constexpr (!TRANS) {
         s = (b_kc[i] < krem) ? b_src[i] + (size_t)kt * (BK * 2) : zsrc;
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
                                        16, 0, 0);
     }
   };
+  auto stage = [&](int buf, int kt) { stage_part(buf, kt, -1); };
 
   f32x16 acc[TN][TM];
 #pragma unroll
@@ -195,16 +203,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; every wave finished reading tile kt-1
     asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      stage(nb, kt + STAGES - 1);  // refills the slot tile kt-1 occupied
-    }
+    const bool prefetch = kt + STAGES - 1 < nk;
+    int nb = buf + STAGES - 1;
+    if (nb >= STAGES) nb -= STAGES;  // the slot tile kt-1 occupied
+    if (!PIPE && prefetch) stage(nb, kt + STAGES - 1);
     const char* abase = smem + buf * STAGE_BYTES;
     const char* bbase = abase + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 wf[TN], xf[TM];
+
+    auto load_frags = [&](int ks, bf16x8* wf, bf16x8* xf) {
       if constexpr (!TRANS) {
         const int coff = ((2 * ks + hi) ^ sw) << 4;
 #pragma unroll
@@ -238,11 +244,32 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
           xf[j] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
+    };
+
+    if constexpr (PIPE) {
+      bf16x8 wf[2][TN], xf[2][TM];
+      load_frags(0, wf[0], xf[0]);
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) load_frags(ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+        if (prefetch) stage_part(nb, kt + STAGES - 1, ks);
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wf[TN], xf[TM];
+        load_frags(ks, wf, xf);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
     }
     if (++buf == STAGES) buf = 0;
   }
@@ -333,11 +360,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS, bool PIPE = false>
 static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
   constexpr int LDS = STAGES * (BM + BN) * 64 * 2;
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, TRANS>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, TRANS, PIPE>;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
@@ -359,6 +386,8 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
       case 2: return launch_cfg<256, 128, 4, 2, 2, EPI, true>(a, splits, s);
       case 3: return launch_cfg<256, 128, 4, 2, 3, EPI, true>(a, splits, s);
       case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, true>(a, splits, s);
+      case 21: return launch_cfg<128, 128, 4, 2, 2, EPI, true, true>(a, splits, s);
+      case 16: return launch_cfg<128, 128, 2, 2, 2, EPI, true, true>(a, splits, s);
       default: return launch_cfg<128, 128, 2, 2, 2, EPI, true>(a, splits, s);
     }
   } else {
@@ -369,6 +398,9 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
       case 4: return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, splits, s);
       case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, false>(a, splits, s);
       case 6: return launch_cfg<128, 128, 2, 2, 4, EPI, false>(a, splits, s);
+      case 16: return launch_cfg<128, 128, 2, 2, 2, EPI, false, true>(a, splits, s);
+      case 18: return launch_cfg<256, 128, 4, 2, 2, EPI, false, true>(a, splits, s);
+      case 21: return launch_cfg<128, 128, 4, 2, 2, EPI, false, true>(a, splits, s);
       default: return launch_cfg<128, 128, 2, 2, 2, EPI, false>(a, splits, s);
     }
   }
@@ -379,7 +411,8 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (M < 128 || N < 128) return 0;
   if (splits > 1) return 3;                     // split-K wgrad: long K, few tiles -> 256x128, 3 stages
-  if (K >= 4096) return 2;                      // long-K dgrad: 256x128
+  static const int pipe_min_k = getenv("VTP_GEMM_PIPE_MINK") ? atoi(getenv("VTP_GEMM_PIPE_MINK")) : 4096;
+  if (K >= pipe_min_k) return 21;                     // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between the MFMAs); A/B-neutral below 4096
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
 }
@@ -459,7 +492,7 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   splits = (K + ks - 1) / ks;
   // tools/gemm_tn_bench.py on MI355X: the 8-wave 128x128 tile wins on every wgrad shape (transpose reads want more waves)
   int cfg = g_force_cfg >= 0 ? g_force_cfg : 5;
-  if (cfg != 2 && cfg != 3 && cfg != 5) cfg = 0;
+  if (cfg != 2 && cfg != 3 && cfg != 5 && cfg != 16 && cfg != 21) cfg = 0;
   hipStream_t s = (hipStream_t)stream;
   if (epilogue == VTP_EPI_F32) return launch_gemm<EPI_F32, true>(a, 1, cfg, s);
   return launch_gemm<EPI_F32_SLAB, true>(a, splits, cfg, s);
