@@ -356,10 +356,22 @@ class Stack:
             b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
             self.blocks.append(b)
 
+    @staticmethod
+    def _rows(segs):
+        """(first row, B, N, rope) of every segment of a row-concatenated token buffer."""
+        r0 = 0
+        for B, N, rope in segs:
+            yield r0, B, N, rope
+            r0 += B * N
+
     # x: f32 [M, D] input residual.  Returns the output residual (f32 [M, D]).
-    def forward(self, ws: Workspace, x, B: int, N: int, rope, prefix_tokens: int, train: bool):
+    def forward(self, ws: Workspace, x, B: int, N: int, rope, prefix_tokens: int, train: bool, segs=None):
+        """`segs` = [(B_i, N_i, rope_i)]: several batches of different sequence length concatenated along the token-row
+        axis (the reference's list path, block.py:235-298 / utils.py:14-25 cat_keep_shapes): every linear / norm runs once
+        over all rows, RoPE and attention run per segment on its row range."""
         D, H, heads = self.D, self.H, self.heads
-        M = B * N
+        segs = [(B, N, rope)] if segs is None else segs
+        M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
         saved_all = []
@@ -369,7 +381,7 @@ class Stack:
             st1 = ws.get(t + "st1", (M, 2), F32)
             qkv = ws.get(t + "qkv", (M, 3 * D), BF)
             o = ws.get(t + "o", (M, D), BF)
-            lse = ws.get(t + "lse", (B, heads, N), F32)
+            lse = ws.get(t + "lse", (M * heads,), F32)  # per segment [B_i, heads, N_i]
             xmid = ws.get(t + "xmid", (M, D), F32)
             xn2 = ws.get(t + "xn2", (M, D), BF)
             st2 = ws.get(t + "st2", (M, 2), F32)
@@ -380,9 +392,12 @@ class Stack:
 
             ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
             ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
-            if rope is not None:
-                ops.rope_qk(qkv, rope[0], rope[1], B, N, heads, prefix_tokens)
-            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, N, heads, N * 3 * D, 3 * D, N * D, D, scale, self.causal)
+            for r0, Bs, Ns, rp in self._rows(segs):
+                q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
+                if rp is not None:
+                    ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
+                ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o_s, lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D,
+                             scale, self.causal)
             ops.gemm_nt(o, b.proj.w, xmid, M=M, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, resid=x, epi=EPI_F32)
             ops.norm_fwd(xmid, b.n2w, b.n2b, xn2, st2, M, D, self.eps, self.kind)
             if vit:
@@ -397,11 +412,12 @@ class Stack:
         return x
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
-    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None):
+    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None, segs=None):
         """Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
         gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input."""
         D, H, heads = self.D, self.H, self.heads
-        M = B * N
+        segs = [(B, N, rope)] if segs is None else segs
+        M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
         dh = ws.get("b.dh", (M, H), BF)
@@ -409,7 +425,7 @@ class Stack:
         dxn = ws.get("b.dxn", (M, D), BF)
         d_o = ws.get("b.do", (M, D), BF)
         dqkv = ws.get("b.dqkv", (M, 3 * D), BF)
-        delta = ws.get("b.delta", (B, heads, N), F32)
+        delta = ws.get("b.delta", (M * heads,), F32)
         dmid = ws.get("b.dmid", (M, D), F32)
         dmid_b = ws.get("b.dmid_b", (M, D), BF)
         saved = self.last_saved if saved is None else saved
@@ -431,10 +447,13 @@ class Stack:
             ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind)
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
             linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o)
-            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, d_o, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], B, N, heads,
-                         N * 3 * D, 3 * D, N * D, D, scale, self.causal)
-            if rope is not None:
-                ops.rope_qk(dqkv, rope[0], rope[1], B, N, heads, prefix_tokens, inverse=True)
+            for r0, Bs, Ns, rp in self._rows(segs):
+                r1 = r0 + Bs * Ns
+                q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
+                ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
+                             dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal)
+                if rp is not None:
+                    ops.rope_qk(dq_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens, inverse=True)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
             ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
             dy, dy_b = dxo, dxo_b
@@ -489,8 +508,7 @@ class TrunkEngine:
             if store.has(self.prefix + "feature_bottleneck.weight") else None
         self.ws: Dict[tuple, Workspace] = {}
 
-    def workspace(self, B, Hh, Ww, tag: str = "") -> Workspace:
-        key = (B, Hh, Ww, tag)
+    def workspace(self, key) -> Workspace:
         if key not in self.ws:
             self.ws[key] = Workspace(self.store.device)
         return self.ws[key]
@@ -499,69 +517,102 @@ class TrunkEngine:
         """img f32 [B,3,H,W] -> final-norm tokens xnf bf16 [B*N, D] (N = 1 + hw).  masks: uint8 [B, hw] (1 = replace the
         patch embedding by mask_token, vision_transformer.py:194-196).  `tag` separates the buffers of passes that are in
         flight at the same time with the same shape; self.ctx() returns the handle backward() needs for such passes."""
+        return self.forward_list([(img, masks)], train, tag)
+
+    def forward_list(self, items, train: bool, tag: str = ""):
+        """items = [(img f32 [B_i,3,H_i,W_i], masks_i or None)]: the reference's list forward (forward_features_list,
+        vision_transformer.py:221-258): batches of different resolution go through the blocks as ONE row-concatenated
+        token buffer (one GEMM / norm launch per layer for all of them, attention + RoPE per segment).  Returns xnf bf16
+        [sum_i B_i*N_i, D]; ctx().segs[i].row0 is the first row of item i."""
         st = self.store
-        B, _, Hh, Ww = img.shape
-        h, w = Hh // 16, Ww // 16
-        hw, N, D = h * w, h * w + 1, self.D
-        M = B * N
-        ws = self.workspace(B, Hh, Ww, tag)
-        patches = ws.get("patches", (B * hw, 768), BF)
+        D = self.D
+        segs, r0, p0 = [], 0, 0
+        for img, masks in items:
+            B, _, Hh, Ww = img.shape
+            h, w = Hh // 16, Ww // 16
+            sg = TrunkSeg()
+            sg.B, sg.h, sg.w, sg.hw, sg.N, sg.row0, sg.prow0, sg.masks, sg.img = B, h, w, h * w, h * w + 1, r0, p0, masks, img
+            sg.rope = rope_tables(self.periods, h, w, st.device)
+            segs.append(sg)
+            r0 += B * sg.N
+            p0 += B * sg.hw
+        M, P = r0, p0
+        ws = self.workspace((tuple((g.B, g.h, g.w) for g in segs), tag))
+        patches = ws.get("patches", (P, 768), BF)
         x0 = ws.get("x0", (M, D), F32)
-        ops.im2col16(img, patches, B, Hh, Ww)
-        ops.gemm_nt(patches, self.pe.w, x0, M=B * hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(hw, 1))
-        ops.assemble_tokens(x0, st.p(self.prefix + "cls_token"), st.p(self.prefix + "mask_token"), masks, B, N, D)
-        rope = rope_tables(self.periods, h, w, st.device)
-        xl = self.stack.forward(ws, x0, B, N, rope, 1, train)
+        for g in segs:
+            pt, xs = patches[g.prow0:g.prow0 + g.B * g.hw], x0[g.row0:g.row0 + g.B * g.N]
+            ops.im2col16(g.img, pt, g.B, g.h * 16, g.w * 16)
+            ops.gemm_nt(pt, self.pe.w, xs, M=g.B * g.hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(g.hw, 1))
+            ops.assemble_tokens(xs, st.p(self.prefix + "cls_token"), st.p(self.prefix + "mask_token"), g.masks, g.B, g.N, D)
+        stack_segs = [(g.B, g.N, g.rope) for g in segs]
+        xl = self.stack.forward(ws, x0, 0, 0, None, 1, train, segs=stack_segs)
         xnf = ws.get("xnf", (M, D), BF)
         stf = ws.get("stf", (M, 2), F32)
         ops.norm_fwd(xl, st.p(self.prefix + "norm.weight"), st.p(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf,
                      M, D, self.eps, self.kind)
-        self._ctx = (ws, B, h, w, xl, xnf, stf, rope, patches, masks, self.stack.last_saved, x0)
+        c = TrunkCtx()
+        c.ws, c.segs, c.M, c.xl, c.xnf, c.stf, c.patches, c.stack_saved, c.x0, c.stack_segs = \
+            ws, segs, M, xl, xnf, stf, patches, self.stack.last_saved, x0, stack_segs
+        self._ctx = c
         return xnf
 
     def ctx(self):
         return self._ctx
 
-    def latents(self, out_f32: bool = False) -> torch.Tensor:
-        """bottleneck on the patch rows of the last forward -> [B*hw, 64] (bf16, or f32 for the API boundary)."""
-        ws, B, h, w, _, xnf = self._ctx[:6]
-        hw = h * w
-        lat = ws.get("lat32" if out_f32 else "lat", (B * hw, self.bott_dim), F32 if out_f32 else BF)
-        ops.gemm_nt(xnf, self.bott.w, lat, M=B * hw, N=self.bott_dim, K=self.D, epi=EPI_F32 if out_f32 else EPI_BF16,
-                    a_remap=(hw, 1))
+    def latents(self, out_f32: bool = False, seg: int = 0) -> torch.Tensor:
+        """bottleneck on the patch rows of item `seg` of the last forward -> [B*hw, 64] (bf16, or f32 for the API)."""
+        c = self._ctx
+        g = c.segs[seg]
+        lat = c.ws.get("lat32" if out_f32 else "lat", (g.B * g.hw, self.bott_dim), F32 if out_f32 else BF)
+        ops.gemm_nt(c.xnf[g.row0:], self.bott.w, lat, M=g.B * g.hw, N=self.bott_dim, K=self.D,
+                    epi=EPI_F32 if out_f32 else EPI_BF16, a_remap=(g.hw, 1))
         return lat
 
     def d_xnf_buffer(self, ctx=None) -> torch.Tensor:
-        """bf16 [B*N, D] gradient w.r.t. the final-norm tokens of the last forward.  Patch rows are written by
-        backward() (bottleneck dgrad); cls rows are zero unless a cls-path head (CLIP) writes them before backward()."""
-        ws, B, h, w = (self._ctx if ctx is None else ctx)[:4]
-        return ws.get("b.d_xnf", (B * (h * w + 1), self.D), BF, zero=True)
+        """bf16 [M, D] gradient w.r.t. the final-norm tokens of the last forward (all items, row-concatenated).  The patch
+        rows of the latent item are written by backward() (bottleneck dgrad); every other row must be written (or zeroed)
+        by the heads before backward()."""
+        c = self._ctx if ctx is None else ctx
+        return c.ws.get("b.d_xnf", (c.M, self.D), BF, zero=True)
 
-    def backward(self, d_lat: Optional[torch.Tensor], ctx=None):
-        """d_lat: bf16 [B*hw, 64] grad of latents().  Accumulates every trunk parameter gradient into store.flat_g.
-        Generator (see Stack.backward): yields "tail", then ("block", i) per block."""
+    def backward(self, d_lat: Optional[torch.Tensor], ctx=None, lat_seg: int = 0):
+        """d_lat: bf16 [B*hw, 64] grad of latents(seg=lat_seg), or None.  Accumulates every trunk parameter gradient into
+        store.flat_g.  Generator (see Stack.backward): yields "tail", then ("block", i) per block."""
         st = self.store
         if ctx is not None:
             self._ctx = ctx
-        ws, B, h, w, xl, xnf, stf, rope, patches, masks, stack_saved, _ = self._ctx
-        hw, N, D = h * w, h * w + 1, self.D
-        M = B * N
+        c = self._ctx
+        ws, M, D = c.ws, c.M, self.D
         d_xnf = ws.get("b.d_xnf", (M, D), BF, zero=True)  # rows stay zero unless a head wrote them before backward()
         if d_lat is not None:
-            linear_bwd(ws, "bott", self.bott, d_lat, xnf, B * hw, d_xnf, x_remap=(hw, 1), dx_remap=(hw, 1))
+            g = c.segs[lat_seg]
+            linear_bwd(ws, "bott", self.bott, d_lat, c.xnf[g.row0:], g.B * g.hw, d_xnf[g.row0:], x_remap=(g.hw, 1),
+                       dx_remap=(g.hw, 1))
         dx = ws.get("b.dxt", (M, D), F32)
         dx_b = ws.get("b.dxt_b", (M, D), BF)
-        ops.norm_bwd(d_xnf, xl, st.p(self.prefix + "norm.weight"), stf, None, dx, dx_b, st.g(self.prefix + "norm.weight"),
+        ops.norm_bwd(d_xnf, c.xl, st.p(self.prefix + "norm.weight"), c.stf, None, dx, dx_b, st.g(self.prefix + "norm.weight"),
                      st.g(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, N, rope, 1, stack_saved)
-        if masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
-            ops.mask_rows_bwd(dx0, dx0_b, masks, st.g(self.prefix + "mask_token"), B, N, D)
-        # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
-        linear_bwd(ws, "pe", self.pe, dx0_b, patches, B * hw, None, need_dx=False, dy_remap=(hw, 1))
-        ops.strided_rowsum(dx0, N * D, st.g(self.prefix + "cls_token"), B, D)
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs)
+        for g in c.segs:
+            d_s, d_sb = dx0[g.row0:g.row0 + g.B * g.N], dx0_b[g.row0:g.row0 + g.B * g.N]
+            if g.masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
+                ops.mask_rows_bwd(d_s, d_sb, g.masks, st.g(self.prefix + "mask_token"), g.B, g.N, D)
+            # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
+            linear_bwd(ws, "pe", self.pe, d_sb, c.patches[g.prow0:g.prow0 + g.B * g.hw], g.B * g.hw, None, need_dx=False,
+                       dy_remap=(g.hw, 1))
+            ops.strided_rowsum(d_s, g.N * D, st.g(self.prefix + "cls_token"), g.B, D)
         OVERLAP.join()
+
+
+class TrunkSeg:
+    """One item of a list forward: B images of (16h x 16w) pixels -> rows [row0, row0 + B*N) of the token buffers."""
+
+
+class TrunkCtx:
+    """Saved state of one trunk forward (what backward() needs)."""
 
 
 # =====================================================================================================================

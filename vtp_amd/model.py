@@ -296,7 +296,7 @@ class VTPModel(nn.Module):
             wb = self.trunk.feature_bottleneck.weight
             patch_t = self._trunk.latents(out_f32=True).view(B, hw, -1).clone()
             cls_b = torch.empty(B, wb.shape[0], dtype=torch.float32, device=img.device)
-            ops.gemm_nt(self._trunk.ctx()[5], self._trunk.bott.w, cls_b, M=B, N=wb.shape[0], K=wb.shape[1],
+            ops.gemm_nt(self._trunk.ctx().xnf, self._trunk.bott.w, cls_b, M=B, N=wb.shape[0], K=wb.shape[1],
                         lda=(hw + 1) * wb.shape[1], epi=ops.EPI_F32)
             cls_t = cls_b
         return {"cls_token": cls_t.contiguous(), "patch_tokens": patch_t.contiguous()}

@@ -181,15 +181,16 @@ class VTPTrainer:
             result = stop.value
         return result
 
-    def _ssl_gen(self, P):
-        """SSL leg of the step (teacher forward, student global+local forward, DINO + iBOT loss, head and trunk backward).
-        The trunk gradients it produces are completed by the rec/clip pass that follows, so only the DINO-head bucket is
-        announced here."""
+    def _ssl_gen(self, P, lead_images=None):
+        """SSL leg of the step: teacher forward, ONE student list forward (lead images of the rec / clip objectives +
+        masked global crops + local crops), DINO + iBOT loss, head backward, and the scatter of the head's input gradient
+        into the trunk's d_xnf rows.  The trunk backward itself is run once by the caller, over all items.  Returns the
+        ssl_forward() dict."""
         from .vtp import ssl_forward
         model, st, head = self.model, self.store, self.ssl_head
         dist = self.bucketer.dist
         K, D = head.K, self.trunk.D
-        out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True)
+        out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
         Tt, Ts, Tm, B2, nl = out["Tt"], out["Ts"], out["Tm"], out["B2"], out["nl"]
         n_masked = P["plan"]["n_masked"]
         ws = out["ws"]
@@ -213,16 +214,13 @@ class VTPTrainer:
                     d_logits, Ts, K)
         dX = head.backward(d_logits, out["head_ctx"])
         yield ["dino_head"]
-        d_l = self.trunk.d_xnf_buffer(out["ctx_l"])
-        d_g = self.trunk.d_xnf_buffer(out["ctx_g"])
-        d_l.zero_()
-        d_g.zero_()
-        ops.scatter_token_rows(dX, P["dev"]["student_local_src"], d_l, nl, D)
-        ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_g, Ts - nl, D)
-        for _ in self.trunk.backward(None, ctx=out["ctx_l"]):
-            pass
-        for _ in self.trunk.backward(None, ctx=out["ctx_g"]):
-            pass
+        ctx = out["ctx"]
+        d_xnf = self.trunk.d_xnf_buffer(ctx)
+        d_xnf.zero_()
+        seg_g, seg_l = ctx.segs[-2], ctx.segs[-1]
+        ops.scatter_token_rows(dX, P["dev"]["student_local_src"], d_xnf[seg_l.row0:], nl, D)
+        ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_xnf[seg_g.row0:], Ts - nl, D)
+        return out
 
     def prepare_ssl(self, global_crops: torch.Tensor, local_crops: torch.Tensor, masks) -> dict:
         """Host-side preparation of one SSL batch (index plan + device copies); call outside the timed / captured region.
@@ -249,16 +247,17 @@ class VTPTrainer:
         st.zero_grad()
         self.loss_sum.zero_()
         self.clip_loss_sum.zero_()
-        if ssl is not None:
+        if ssl is not None:  # one student list forward: [images | masked global crops | local crops]
             self.ssl_loss_sum.zero_()
-            yield from self._ssl_gen(ssl)
-        xnf = self.trunk.forward(images, train=True)
+            xnf = (yield from self._ssl_gen(ssl, lead_images=images))["xnf"][:B * N]  # rows of the lead item
+        else:
+            xnf = self.trunk.forward(images, train=True)
         lat = self.trunk.latents()
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
         ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
         if text is not None:
-            d_xnf = self.trunk.d_xnf_buffer()
+            d_xnf = self.trunk.d_xnf_buffer()[:B * N]  # rows of the lead item
             cw = self.clip.ws
             Dt = self.clip.Dt
             f_img = self.clip.image_features(xnf, B, N)

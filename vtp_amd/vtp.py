@@ -125,9 +125,13 @@ def plan_to_device(plan, device):
     return d
 
 
-def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_plan=None, train: bool = False):
+def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_plan=None, train: bool = False,
+                lead_images=None):
     """Teacher + student forward of one SSL batch (vtp.py:410-484).  Returns a dict with the head logits and the
-    contexts the backward needs.  masks_u8: uint8 [2B, hw] on the device; plan: build_ssl_indices() output."""
+    context the backward needs.  masks_u8: uint8 [2B, hw] on the device; plan: build_ssl_indices() output.
+    The student's passes (masked global crops, local crops and -- when `lead_images` is given -- the clean images of the
+    rec / clip objectives, which use the same trunk weights) go through the trunk as ONE list forward (item order:
+    lead, global, local)."""
     st = model._store
     B2 = global_crops.shape[0]
     hw = (global_crops.shape[-2] // 16) * (global_crops.shape[-1] // 16)
@@ -145,14 +149,14 @@ def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_pla
     ops.gather_token_rows(xnf_t, idx["teacher_src"], Xt, Tt, D)
     t_logits, _ = model._t_head.forward(Xt, Tt, tag="teacher")
     # ---- student: masked global crops + local crops through the SAME trunk weights (vtp.py:452-484)
-    xnf_g = model._trunk.forward(global_crops, train=train, masks=masks_u8, tag="ssl_g")
-    ctx_g = model._trunk.ctx()
-    xnf_l = model._trunk.forward(local_crops, train=train, tag="ssl_l")
-    ctx_l = model._trunk.ctx()
+    items = ([(lead_images, None)] if lead_images is not None else []) + [(global_crops, masks_u8), (local_crops, None)]
+    xnf = model._trunk.forward_list(items, train=train, tag="ssl")
+    ctx = model._trunk.ctx()
+    seg_g, seg_l = ctx.segs[-2], ctx.segs[-1]
     nl = int(plan["student_local_src"].shape[0])
     Xs = ws.get("Xs", (Ts, D), BF)
-    ops.gather_token_rows(xnf_l, idx["student_local_src"], Xs, nl, D)
-    ops.gather_token_rows(xnf_g, idx["student_global_src"], Xs[nl:], Ts - nl, D)
+    ops.gather_token_rows(xnf[seg_l.row0:], idx["student_local_src"], Xs, nl, D)
+    ops.gather_token_rows(xnf[seg_g.row0:], idx["student_global_src"], Xs[nl:], Ts - nl, D)
     s_logits, head_ctx = model._head.forward(Xs, Ts, tag="student")
-    return dict(teacher_logits=t_logits, student_logits=s_logits, head_ctx=head_ctx, ctx_g=ctx_g, ctx_l=ctx_l, idx=idx,
+    return dict(teacher_logits=t_logits, student_logits=s_logits, head_ctx=head_ctx, ctx=ctx, xnf=xnf, idx=idx,
                 Xs=Xs, student_global_cls=Xs[nl:nl + B2], Tt=Tt, Ts=Ts, Tm=Tm, nl=nl, B2=B2, N=N, ws=ws)
