@@ -26,6 +26,10 @@ CFGS = {0: "128x128 4w s2", 16: "128x128 4w s2 PIPE", 5: "128x128 8w s2", 21: "1
 
 
 def main():
+    global SHAPES
+    if len(sys.argv) > 1:  # python tools/gemm_bench.py <M>: the forward / dgrad shapes at another row count
+        M2 = int(sys.argv[1])
+        SHAPES = [(t, M2, n, k, e) for t, m, n, k, e in SHAPES if m == 8224]
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)

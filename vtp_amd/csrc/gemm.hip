@@ -82,14 +82,20 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
 
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int wg = blockIdx.x;
-  if (p.xcd_swizzle) {  // bijective: XCD x (= block % 8) gets a contiguous chunk of the tile list
-    const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, x = wg & 7;
-    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
-  }
-  const int tile_n = wg % tiles_n;  // n fastest: a chunk = a band of output rows x all weight panels
-  const int tile_m = wg / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;  // persistent: G <= ntiles workgroups, workgroup b owns tiles b, b + G, b + 2G, ...
+  const int n_my = (ntiles - (int)blockIdx.x + G - 1) / G;
+  // i-th tile of this workgroup -> output origin.  XCD x (= workgroup % 8; G is a multiple of 8 whenever G < ntiles)
+  // walks a contiguous chunk of the tile list, n fastest: a chunk = a band of output rows x all weight panels.
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    int wg = blockIdx.x + i * G;
+    if (p.xcd_swizzle) {  // bijective on [0, ntiles)
+      const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
+      wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+    }
+    n0 = (wg % tiles_n) * BN;
+    m0 = (wg / tiles_n) * BM;
+  };
   const int kbeg = blockIdx.z * p.k_split;
   const int kend = min(p.K, kbeg + p.k_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -101,45 +107,47 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   const char* b_src[PB];
   int a_kc[PA], b_kc[PB];  // NT: this lane's source k offset (elements) inside the k-tile | TRANS: tile row (k) of the piece
   const char* zsrc = (const char*)g_zero_block;
-  if constexpr (!TRANS) {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int row = (wave * PA + i) * 8 + prow;
-      const int c = slot ^ ((row >> 1) & 7);
-      int m = min(m0 + row, p.M - 1);
-      m = remap_row(m, p.a_grp, p.a_pre);
-      a_src[i] = (const char*)(p.A + (size_t)m * p.lda + kbeg + c * 8);
-      a_kc[i] = c * 8;
+  auto set_src = [&](int m0, int n0) {
+    if constexpr (!TRANS) {
+  #pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * 8 + prow;
+        const int c = slot ^ ((row >> 1) & 7);
+        int m = min(m0 + row, p.M - 1);
+        m = remap_row(m, p.a_grp, p.a_pre);
+        a_src[i] = (const char*)(p.A + (size_t)m * p.lda + kbeg + c * 8);
+        a_kc[i] = c * 8;
+      }
+  #pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int row = (wave * PB + i) * 8 + prow;
+        const int c = slot ^ ((row >> 1) & 7);
+        const int n = min(n0 + row, p.N - 1);
+        b_src[i] = (const char*)(p.B + (size_t)n * p.ldb + kbeg + c * 8);
+        b_kc[i] = c * 8;
+      }
+    } else {
+      // piece q of a [64 k][W cols] tile: byte q*1024 + lane*16 -> tile row r, stored slot s' ; source chunk s = s' ^ 4*(r&3)
+  #pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int byte = (wave * PA + i) * 1024 + lane * 16;
+        const int r = byte / (BM * 2);
+        const int sp = (byte % (BM * 2)) >> 4;
+        const int col = m0 + ((sp ^ (4 * (r & 3))) << 3);
+        a_kc[i] = r;
+        a_src[i] = col < p.M ? (const char*)(p.A + col) : nullptr;  // column base; the token row is added per stage
+      }
+  #pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int byte = (wave * PB + i) * 1024 + lane * 16;
+        const int r = byte / (BN * 2);
+        const int sp = (byte % (BN * 2)) >> 4;
+        const int col = n0 + ((sp ^ (4 * (r & 3))) << 3);
+        b_kc[i] = r;
+        b_src[i] = col < p.N ? (const char*)(p.B + col) : nullptr;
+      }
     }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int row = (wave * PB + i) * 8 + prow;
-      const int c = slot ^ ((row >> 1) & 7);
-      const int n = min(n0 + row, p.N - 1);
-      b_src[i] = (const char*)(p.B + (size_t)n * p.ldb + kbeg + c * 8);
-      b_kc[i] = c * 8;
-    }
-  } else {
-    // piece q of a [64 k][W cols] tile: byte q*1024 + lane*16 -> tile row r, stored slot s' ; source chunk s = s' ^ 4*(r&3)
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int byte = (wave * PA + i) * 1024 + lane * 16;
-      const int r = byte / (BM * 2);
-      const int sp = (byte % (BM * 2)) >> 4;
-      const int col = m0 + ((sp ^ (4 * (r & 3))) << 3);
-      a_kc[i] = r;
-      a_src[i] = col < p.M ? (const char*)(p.A + col) : nullptr;  // column base; the token row is added per stage
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int byte = (wave * PB + i) * 1024 + lane * 16;
-      const int r = byte / (BN * 2);
-      const int sp = (byte % (BN * 2)) >> 4;
-      const int col = n0 + ((sp ^ (4 * (r & 3))) << 3);
-      b_kc[i] = r;
-      b_src[i] = col < p.N ? (const char*)(p.B + col) : nullptr;
-    }
-  }
+  };
 
   // q < 0: issue every piece of the tile; q in 0..3: only the pieces j with j % 4 == q (A pieces are j = 0..PA-1)
   auto stage_part = [&](int buf, int kt, int q) {
@@ -189,24 +197,56 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   const int sw = (lane >> 1) & 7;
   const int rowoff = (lane & 31) * 128;
 
-  // prologue: STAGES-1 tiles in flight
+  // staging cursor: the (tile, k-tile) whose LDS-DMA is issued next.  It runs STAGES-1 k-tiles ahead of the compute cursor
+  // ACROSS tile boundaries, so a tile's first k-tiles stream in while the previous tile finishes and stores its output.
+  int s_i = 0, s_kt = 0;
+  {
+    int m0s, n0s;
+    tile_origin(0, m0s, n0s);
+    set_src(m0s, n0s);
+  }
+  auto advance = [&]() {
+    if (++s_kt == nk) {
+      s_kt = 0;
+      if (++s_i < n_my) {
+        int m0s, n0s;
+        tile_origin(s_i, m0s, n0s);
+        set_src(m0s, n0s);
+      }
+    }
+  };
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) stage(s, s);
+    if (s_i < n_my) {
+      stage(s, s_kt);
+      advance();
+    }
 
-  int buf = 0;  // ring slot of tile kt
+  int buf = 0;     // ring slot of the k-tile being computed
+  int landed = 0;  // k-tiles already known to be in LDS (all DMA drained before the previous tile's output stores)
+  for (int ti = 0; ti < n_my; ++ti) {
+  int m0, n0;
+  tile_origin(ti, m0, n0);
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most (tiles issued after it) * P of this wave's DMA pieces are still outstanding
-    const int later = min(STAGES - 2, nk - 1 - kt);
-    if (later >= 2) wait_vmcnt<2 * P>();
-    else if (later == 1) wait_vmcnt<P>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; every wave finished reading tile kt-1
+    // k-tile (ti, kt) has landed once at most (k-tiles issued after it) * P of this wave's DMA pieces are outstanding
+    if (landed > 0) {
+      --landed;
+    } else {
+      const int rem = (n_my - 1 - ti) * nk + (nk - 1 - kt);
+      const int later = min(STAGES - 2, rem);
+      if (later >= 2) wait_vmcnt<2 * P>();
+      else if (later == 1) wait_vmcnt<P>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of this k-tile landed; every wave finished reading the previous one
     asm volatile("" ::: "memory");
-    const bool prefetch = kt + STAGES - 1 < nk;
+    const bool prefetch = s_i < n_my;
     int nb = buf + STAGES - 1;
-    if (nb >= STAGES) nb -= STAGES;  // the slot tile kt-1 occupied
-    if (!PIPE && prefetch) stage(nb, kt + STAGES - 1);
+    if (nb >= STAGES) nb -= STAGES;  // the slot the previous k-tile occupied
+    if (!PIPE && prefetch) {
+      stage(nb, s_kt);
+      advance();
+    }
     const char* abase = smem + buf * STAGE_BYTES;
     const char* bbase = abase + A_BYTES;
 
@@ -252,13 +292,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) load_frags(ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
-        if (prefetch) stage_part(nb, kt + STAGES - 1, ks);
+        if (prefetch) stage_part(nb, s_kt, ks);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
       }
+      if (prefetch) advance();
     } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -272,6 +313,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
       }
     }
     if (++buf == STAGES) buf = 0;
+  }
+  if (ti + 1 < n_my) {
+    // drain the DMA of the next tile's first k-tiles (issued up to a k-tile ago: all but landed) BEFORE the output stores,
+    // so that the stores -- which share vmcnt -- never sit in front of a load the next iterations wait for
+    wait_vmcnt<0>();
+    landed = min(STAGES - 1, (n_my - 1 - ti) * nk);
   }
 
   // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
@@ -358,6 +405,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }  // tile loop
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, bool TRANS, bool PIPE = false>
@@ -369,7 +423,20 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), 1, splits);
+  static int slots = 0;  // resident workgroups the device holds of this kernel (CUs x occupancy)
+  if (!slots) {
+    int occ = 1, dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * WAVES_M * WAVES_N, LDS);
+    slots = prop.multiProcessorCount * (occ < 1 ? 1 : occ);
+    slots -= slots % 8;
+    if (getenv("VTP_GEMM_PERSIST") && atoi(getenv("VTP_GEMM_PERSIST")) == 0) slots = 1 << 30;
+  }
+  const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+  // persistent when the tile list exceeds one resident wave of workgroups and the split-K factor is 1
+  dim3 grid(splits == 1 && ntiles > slots ? slots : ntiles, 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), LDS, s, a);
   return check_launch(TRANS ? "gemm_tn" : "gemm_nt");
 }
@@ -411,8 +478,12 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (M < 128 || N < 128) return 0;
   if (splits > 1) return 3;                     // split-K wgrad: long K, few tiles -> 256x128, 3 stages
+  // big-M GEMMs (the row-concatenated list forward, M = 34k): 256x256 tiles halve the LDS / L2 traffic per flop; they
+  // need >= 1.5 resident waves of tiles to beat the 128x128 kernels' finer quantisation (tools/gemm_bench.py 34144)
+  static const int big_tiles = getenv("VTP_GEMM_BIG_TILES") ? atoi(getenv("VTP_GEMM_BIG_TILES")) : 384;
+  if (cdiv(M, 256) * cdiv(N, 256) >= big_tiles && (N >= 2304 || K >= 2048)) return 4;
   static const int pipe_min_k = getenv("VTP_GEMM_PIPE_MINK") ? atoi(getenv("VTP_GEMM_PIPE_MINK")) : 4096;
-  if (K >= pipe_min_k) return 21;                     // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between the MFMAs); A/B-neutral below 4096
+  if (K >= pipe_min_k) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
 }
