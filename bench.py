@@ -184,38 +184,57 @@ def main():
         elapsed = float(t)
     loss_val, closs_val = float(loss), float(closs)
 
-    # ---- dominant-kernel roofline: one instrumented step, HIP events around every gemm_nt launch (rank 0)
+    # ---- dominant-kernel roofline: one instrumented step, HIP events (recorded on the launch stream) around every launch of
+    # the MFMA GEMM family -- gemm_nt (forward / dgrad) and gemm_tn (wgrad) are the same kernel template (rank 0)
     roof = None
     if rank == 0:
         recs = []
-        orig = ops.gemm_nt
-
-        def timed_gemm(a, b, c, **kw):
-            M = kw.get("M") if kw.get("M") is not None else a.shape[0]
-            K = kw.get("K") if kw.get("K") is not None else a.shape[1]
-            N = kw.get("N") if kw.get("N") is not None else b.shape[0]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(a, b, c, **kw)
-            e1.record()
-            recs.append((2.0 * M * N * K, e0, e1))
-
         import vtp_amd.engine as eng
-        ops.gemm_nt = timed_gemm
-        trainer.use_graphs = False  # the instrumented step launches eagerly (events cannot sit inside a replayed graph)
+        orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn
+
+        def timed(fn):
+            def run(a, b, c, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(a, b, c, **kw)
+                e1.record()
+                M = kw["M"] if kw.get("M") is not None else a.shape[0]
+                K = kw["K"] if kw.get("K") is not None else a.shape[1]
+                N = kw["N"] if kw.get("N") is not None else b.shape[0]
+                recs.append((2.0 * M * N * K, e0, e1))
+            return run
+
+        ops.gemm_nt, ops.gemm_tn = timed(orig_nt), timed(orig_tn)
+        trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
+        overlap_was = eng.OVERLAP.enabled
+        eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
         try:
             trainer.step(img, txt, ssl)
             torch.cuda.synchronize()
         finally:
-            ops.gemm_nt = orig
-        assert eng.ops.gemm_nt is orig
+            ops.gemm_nt, ops.gemm_tn = orig_nt, orig_tn
+            eng.OVERLAP.enabled = overlap_was
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "vtp::gemm_nt_kernel<128,128,*> (bf16 MFMA 32x32x16, all epilogues)",
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and args.workload == "vtp_base_full" and not args.batch:
+            try:  # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes of this command
+                d = json.load(open(pmc))
+                by, n = 0.0, 0
+                for fam in ("gemm_nt", "gemm_tn"):
+                    # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2, MI355X_MICROARCH.md HBM)
+                    by += 1024.0 * (2.0 * d[fam]["FETCH_SIZE"]["sum"] + d[fam]["WRITE_SIZE"]["sum"])
+                    n += d[fam]["FETCH_SIZE"]["dispatches"]
+                traffic, traffic_src = round(by / n), "profiles/r01_pmc_summary.json (separate --pmc passes; bytes per launch)"
+            except (KeyError, ValueError):
+                pass
+        roof = {"bound": "mfma", "kernel": "vtp::gemm_nt_kernel<...> (bf16 MFMA 32x32x16; NT fwd/dgrad + TN wgrad, all tile configs and epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches_per_step": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
-                "gemm_ms_per_step": round(ms, 3), "flop_per_launch_avg": fl / len(recs)}
+                "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
+                "avg_launch_us": round(ms * 1e3 / len(recs), 2), "gemm_ms_per_step": round(ms, 3),
+                "flop_per_launch_avg": fl / len(recs)}
     if world > 1:
         sync()
 
