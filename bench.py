@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
     ap.add_argument("--prototypes", type=int, default=65536, help="DINO head out_dim K (DINOv2 default 65536; unpinned)")
+    ap.add_argument("--perceptual-weight", type=float, default=0.0,
+                    help="> 0: add the LPIPS perceptual term (VGG16, seeded random weights: vgg.pth is a download) to the rec loss")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,7 +159,12 @@ def main():
     B = args.batch or B
     torch.manual_seed(0)
     model = (VTP(VTPConfig(**cfg_kw), dino_out_dim=args.prototypes) if do_ssl else VTPModel(VTPConfig(**cfg_kw))).to(dev)
-    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs)
+    lp = None
+    if args.perceptual_weight > 0:
+        from vtp_amd import LPIPS
+        lp = LPIPS().reset_parameters(0).to(dev)
+    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs, lpips=lp,
+                         perceptual_weight=args.perceptual_weight)
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
     ssl = None
@@ -261,6 +268,13 @@ def main():
         gflop_ref += ssl_trunk + head
         ssl_info = {"prototypes": dh["K"], "masked_tokens": pl["n_masked"], "student_head_rows": pl["Ts"],
                     "global_crops": 2, "local_crops": 8, "local_res": 96, "ssl_loss": round(float(trainer.ssl_loss_sum), 4)}
+    lpips_info = None
+    if lp is not None:  # two VGG forwards (decoded + target) and one input-gradient pass
+        lp_g = 3.0 * lp.forward_gflop(res, res)
+        gflop_img += lp_g
+        gflop_ref += lp_g
+        lpips_info = {"weight": args.perceptual_weight, "train_gflop_per_image": round(lp_g, 1),
+                      "mean_lpips": round(float(trainer.lpips_val.mean()), 5), "weights": "seeded random (vgg.pth unavailable offline)"}
     ips = world * B * args.steps / elapsed
     out = {
         "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload.startswith("vtp_base")
@@ -273,11 +287,12 @@ def main():
                                f"{' + EMA teacher' if do_ssl else ''}) of trunk + pixel_decoder{' + text tower' if clip else ''}"
                                f"{' + DINO head + EMA teacher trunk (2 global + 8 local-96 crops/img, iBOT masks)' if do_ssl else ''}, "
                                f"{B} img/GPU @ {res}x{res}{', 77-token synthetic captions' if clip else ''}, random-init weights; "
-                               "rec and clip share one trunk pass (identical activations at drop rate 0); LPIPS term not included",
+                               "rec and clip share one trunk pass (identical activations at drop rate 0); "
+                               + ("LPIPS perceptual term included" if lp is not None else "LPIPS term not included (--perceptual-weight)"),
                    "launch": "eager" if args.no_graphs else "hipGraph segments", "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
-        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info,
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info,
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
     }

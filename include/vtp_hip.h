@@ -190,6 +190,33 @@ int vtp_dino_ce(const void* student_logits, const void* teacher_probs, const int
 int vtp_center_ema(float* center, const float* col_sum, float inv_count, const float* count_ptr, float momentum, int K,
                    void* stream);  /* count_ptr != NULL: inv_count = 1 / max(*count_ptr, 1) read on the device */
 
+/* ---- LPIPS perceptual distance (reference: vtp/utils/lpips.py:61-175; VGG16 taps relu1_2 .. relu5_3) ----------------------
+ * Activations are zero-bordered NHWC stacks, bf16 [NB, H+2, W+2, C] flattened to pixel rows, preceded and followed by
+ * >= W+3 guard rows of zeros; every pointer below addresses row 0 of the stack (after the guard).
+ *
+ * vtp_conv3x3: y = epilogue(conv3x3_pad1(x)) as an implicit GEMM on the MFMA GEMM kernel.  w bf16 [Cout, taps*Cin] with the
+ *   reduction index ordered (ky, kx, ci); taps = 9, or 1 for rows that are already unfolded (first VGG layer: Cin = 32 =
+ *   27 unfolded values + 5 zeros, replaces nn.Conv2d(3, 64, 3, padding=1)).  mode 0: y = relu(acc + bias), border rows = 0
+ *   (Conv2d + ReLU, lpips.py:131-146).  mode 1 (input gradient; w = flipped-tap transposed weights): y = acc masked by
+ *   relu_mask > 0 (bf16 [rows, Cout], the activation this gradient flows into; NULL = no ReLU in front), border rows = 0. */
+int vtp_conv3x3(const void* x, const void* w, const float* bias, void* y, const void* relu_mask, int NB, int H, int W, int Cin,
+                int Cout, int taps, int mode, void* stream);
+/* first-layer unfold with ScalingLayer (lpips.py:103-114) fused: source = reconstruction tokens bf16 [n*hw, 768] (tok; the
+ * PixelShuffle(16) of pixel_decoder.py:158-161 is folded into the addressing) or an f32 NCHW image [n,3,H,W] (img); exactly
+ * one is non-NULL.  out bf16 [n*(H+2)*(W+2), 32].  shift / scale: host float[3]. */
+int vtp_lpips_unfold3(const void* tok, const float* img, void* out, int n, int H, int W, const float* shift, const float* scale,
+                      void* stream);
+/* dt bf16 [n*hw, 768] += fold(dA bf16 [n*(H+2)*(W+2), 32]) / scale_c: gradient of vtp_lpips_unfold3 w.r.t. tok. */
+int vtp_lpips_fold3_bwd(const void* dA, void* dt, int n, int H, int W, const float* scale, void* stream);
+/* nn.MaxPool2d(2, 2) on the bordered layout; bwd fuses the ReLU mask of Y and an optional tap gradient:
+ * dY = (Y > 0) * (route(dP) + tap), route = first maximum of each 2x2 window in row-major order. */
+int vtp_maxpool2_fwd(const void* in, void* out, int NB, int H, int W, int C, void* stream);
+int vtp_maxpool2_bwd(const void* Y, const void* dP, const void* tap, void* dY, int NB, int H, int W, int C, void* stream);
+/* one LPIPS tap: val[b] += mean_pixels sum_c w_c (f0/|f0| - f1/|f1|)^2_c  (normalize_tensor + NetLinLayer + spatial_average,
+ * lpips.py:84-100,169-175); df0 (bf16, may be NULL) = gscale * d val / d f0, masked by f0 > 0.  f0, f1 bf16 [n*(H+2)*(W+2), C]. */
+int vtp_lpips_tap(const void* f0, const void* f1, const float* w, float* val, void* df0, int n, int H, int W, int C,
+                  float gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,43 @@ SMALL = dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6,
              text_embed_dim=384, text_depth=12, text_num_heads=6,
              decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6)
 BASE = dict()  # VTPConfig() defaults are VTP-Base f16d64 (configuration_vtp.py:70-113)
+
+
+def load_reference_lpips():
+    """The reference's LPIPS class (vtp/utils/lpips.py) made constructible offline: a stub `torchvision.models.vgg16`
+    returns a module whose `.features` has torchvision's VGG16 layer sequence (conv3x3/ReLU/MaxPool indices 0..30) with
+    default-initialised weights, and the HTTP download of vgg.pth (lpips.py:76-82) is replaced by a no-op; the caller
+    loads weights with load_state_dict."""
+    load_reference()
+    import importlib
+    import torch
+    from torch import nn
+
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "models"):
+        tvmod = types.ModuleType("torchvision.models")
+
+        def vgg16(pretrained=False, **kw):
+            cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+            layers, cin = [], 3
+            for v in cfg:
+                if v == "M":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                    cin = v
+            m = nn.Module()
+            m.features = nn.Sequential(*layers)
+            return m
+
+        tvmod.vgg16 = vgg16
+        tv.models = tvmod
+        sys.modules["torchvision.models"] = tvmod
+    for name in ("requests", "tqdm"):
+        try:
+            importlib.import_module(name)
+        except ImportError:  # only used by the download helper
+            sys.modules[name] = types.ModuleType(name)
+    mod = importlib.import_module("vtp.utils.lpips")
+    mod.LPIPS.load_from_pretrained = lambda self, name="vgg_lpips": None
+    return mod.LPIPS

@@ -55,3 +55,17 @@ def test_masked_trunk(ref_model):
         r = ref_model.trunk(img, is_training=True, masks=masks, use_bottleneck=False)
         o = O.trunk_forward(sd, img, 2, use_bottleneck=False, masks=masks)
     torch.testing.assert_close(o["x_norm_patchtokens"], r["x_norm_patchtokens"], rtol=2e-4, atol=2e-5)
+
+
+def test_lpips():
+    """oracle LPIPS == the reference's LPIPS class (vtp/utils/lpips.py) on the same seeded weights, eval mode."""
+    from oracle import lpips_oracle as L
+    from oracle.ref_stubs import load_reference_lpips
+    LPIPS = load_reference_lpips()
+    m = LPIPS(use_dropout=True).eval()
+    sd = L.make_state(3)
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    x0, x1 = torch.rand(2, 3, 32, 48, generator=g) * 2 - 1, torch.rand(2, 3, 32, 48, generator=g) * 2 - 1
+    with torch.no_grad():
+        torch.testing.assert_close(L.lpips(sd, x0, x1), m(x0, x1), rtol=1e-5, atol=1e-7)

@@ -13,6 +13,9 @@ def __getattr__(name):  # lazy: importing the package must not require torch.cud
     if name == "VTP":
         from .vtp import VTP
         return VTP
+    if name == "LPIPS":
+        from .lpips import LPIPS
+        return LPIPS
     if name == "VTPTrainer":
         from .train import VTPTrainer
         return VTPTrainer

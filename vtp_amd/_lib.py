@@ -44,6 +44,12 @@ SIGNATURES = {
     "vtp_softmax_center": [_P, _P, _F, _P, _I, _I, _P],
     "vtp_dino_ce": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     "vtp_center_ema": [_P, _P, _F, _P, _F, _I, _P],
+    "vtp_conv3x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vtp_lpips_unfold3": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "vtp_lpips_fold3_bwd": [_P, _P, _I, _I, _I, _P, _P],
+    "vtp_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "vtp_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vtp_lpips_tap": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vtp_ema_dev": [_P, _P, _L, _P, _P],
     "vtp_embed_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_embed_tokens_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],

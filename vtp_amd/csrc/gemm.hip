@@ -38,9 +38,13 @@ struct GemmArgs {
   int k_split;       // K elements per blockIdx.z slice (multiple of 64)
   int xcd_swizzle;
   float alpha;
+  // 3x3 convolution as an implicit GEMM over a zero-bordered NHWC image stack (vtp_conv3x3): A = [NB*(H+2)*(W+2), conv_cin]
+  // pixel rows, k-tile kt reads tap (kt*64)/conv_cin at row offset (ky-1)*conv_w2 + (kx-1).  conv_cin == 0: plain GEMM.
+  int conv_cin, conv_w2, conv_p, conv_h2;
 };
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
+       EPI_CONV_MASK = 7 };
 
 __device__ __forceinline__ int remap_row(int m, int grp, int pre) {
   if (grp > 0) return m + (m / grp + 1) * pre;
@@ -159,7 +163,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
       if (q >= 0 && (i & 3) != q) continue;
       const char* s;
       if constexpr (!TRANS) {
-        s = (a_kc[i] < krem) ? a_src[i] + (size_t)kt * (BK * 2) : zsrc;
+        if constexpr (EPI == EPI_CONV_RELU || EPI == EPI_CONV_MASK) {
+          long off = (long)kt * (BK * 2);
+          if (p.conv_cin) {  // tap-shifted pixel rows (guard rows above / below the stack absorb the +-(W+3) reach)
+            const int k0 = kt * BK, tap = k0 / p.conv_cin;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            off = ((long)((ky - 1) * p.conv_w2 + (kx - 1)) * p.lda + (k0 - tap * p.conv_cin)) * 2;
+          }
+          s = (a_kc[i] < krem) ? a_src[i] + off : zsrc;
+        } else {
+          s = (a_kc[i] < krem) ? a_src[i] + (size_t)kt * (BK * 2) : zsrc;
+        }
       } else {
         const int t = kbeg + kt * BK + a_kc[i];
         s = (a_kc[i] < krem && a_src[i]) ? a_src[i] + (size_t)remap_row(t, p.a_grp, p.a_pre) * p.lda * 2 : zsrc;
@@ -359,6 +373,32 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
           const int jh = (n1 >> 4) * 8 + (n1 & 7);  // hidden column
           *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + jh) = __builtin_convertvector(hsw, bf16x4);
         }
+      } else if constexpr (EPI == EPI_CONV_RELU || EPI == EPI_CONV_MASK) {
+        // pixel row m of the zero-bordered stack: border rows are written as zeros so the next layer's taps read padding
+        const int r = m % p.conv_p, yy = r / p.conv_w2, xx = r - yy * p.conv_w2;
+        const bool border = yy == 0 || yy == p.conv_h2 - 1 || xx == 0 || xx == p.conv_w2 - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+          if constexpr (EPI == EPI_CONV_RELU) {
+            f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = border ? 0.f : fmaxf(v[e] + b[e], 0.f);
+          } else {  // input gradient: ReLU mask of the layer input (C2 = that activation; null = no ReLU in front)
+            if (p.C2) {
+              bf16x4 a = *(const bf16x4*)((const bf16*)p.C2 + (size_t)mc * p.ldc2 + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = bf2f(a[e]) > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = border ? 0.f : v[e];
+          }
+          *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + n) = __builtin_convertvector(v, bf16x4);
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -492,6 +532,33 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
 
 using namespace vtp;
 
+template <int EPI>
+static int launch_conv(const GemmArgs& a, hipStream_t s) {
+  // M is millions of pixel rows, K = 9*Cin is long: the widest tile the channel count fills
+  if (a.N <= 64) return launch_cfg<256, 64, 4, 2, 2, EPI, false>(a, 1, s);
+  if (a.N <= 128) return launch_cfg<256, 128, 4, 2, 2, EPI, false>(a, 1, s);
+  return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, 1, s);
+}
+
+extern "C" int vtp_conv3x3(const void* x, const void* w, const float* bias, void* y, const void* relu_mask, int NB, int H,
+                           int W, int Cin, int Cout, int taps, int mode, void* stream) {
+  VTP_REQUIRE(x && w && y, "vtp_conv3x3: null operand");
+  VTP_REQUIRE(NB > 0 && H > 0 && W > 0, "vtp_conv3x3: bad shape");
+  VTP_REQUIRE(taps == 9 || taps == 1, "vtp_conv3x3: taps must be 9 (3x3) or 1 (pre-unfolded rows)");
+  VTP_REQUIRE(Cin % 8 == 0 && Cout % 4 == 0 && (taps == 1 || Cin % 64 == 0),
+              "vtp_conv3x3: Cin must be a multiple of 64 (8 for pre-unfolded rows), Cout of 4");
+  VTP_REQUIRE(mode == 0 ? bias != nullptr : true, "vtp_conv3x3: forward mode needs a bias");
+  GemmArgs a{};
+  a.A = (const bf16*)x; a.B = (const bf16*)w; a.C = y; a.C2 = (void*)relu_mask; a.bias = bias;
+  a.M = NB * (H + 2) * (W + 2); a.N = Cout; a.K = taps * Cin;
+  a.lda = Cin; a.ldb = taps * Cin; a.ldc = Cout; a.ldc2 = Cout; a.alpha = 1.f;
+  a.k_split = (a.K + 63) / 64 * 64;
+  a.xcd_swizzle = g_xcd_swizzle;
+  a.conv_cin = taps == 9 ? Cin : 0; a.conv_w2 = W + 2; a.conv_h2 = H + 2; a.conv_p = (H + 2) * (W + 2);
+  hipStream_t s = (hipStream_t)stream;
+  return mode == 0 ? launch_conv<EPI_CONV_RELU>(a, s) : launch_conv<EPI_CONV_MASK>(a, s);
+}
+
 extern "C" int vtp_gemm_splits(int K, int splits) {
   if (splits < 1) splits = 1;
   const int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
@@ -516,7 +583,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   VTP_REQUIRE(splits == 1 || epilogue == VTP_EPI_F32_ATOMIC || epilogue == VTP_EPI_F32_SLAB,
               "vtp_gemm_nt: split-K needs the atomic or slab epilogue");
   VTP_REQUIRE(epilogue != VTP_EPI_F32_SLAB || (ldc2 > 0), "vtp_gemm_nt: slab epilogue needs ldc2 = slab stride / 4 (in float4 units)");
-  GemmArgs a;
+  GemmArgs a{};
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = C2; a.bias = bias; a.gamma = gamma; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = alpha;
@@ -553,7 +620,7 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   VTP_REQUIRE(epilogue == VTP_EPI_F32 || epilogue == VTP_EPI_F32_SLAB, "vtp_gemm_tn: epilogue must be F32 (accumulate via resid) or F32_SLAB");
   VTP_REQUIRE(splits >= 1 && (splits == 1 || epilogue == VTP_EPI_F32_SLAB), "vtp_gemm_tn: split-K needs the slab epilogue");
   VTP_REQUIRE(epilogue != VTP_EPI_F32_SLAB || ldc2 > 0, "vtp_gemm_tn: slab epilogue needs ldc2 = slab stride / 4");
-  GemmArgs a;
+  GemmArgs a{};
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = nullptr; a.bias = nullptr; a.gamma = nullptr; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.b_grp = b_grp; a.b_pre = b_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = 1.f;

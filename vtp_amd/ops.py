@@ -210,3 +210,33 @@ def center_ema(center, col_sum, inv_count, momentum, K, count=None):
 
 def ema_dev(t, s, n, momentum_dev):
     _lib.check(_lib_().vtp_ema_dev(_p(t), _p(s), n, _p(momentum_dev), _s()), "vtp_ema_dev")
+
+
+# ---- LPIPS (vtp_amd/csrc/lpips.hip, conv mode of gemm.hip) ---------------------------------------------------------------
+def _f3(v):
+    import ctypes
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def conv3x3(x, w, bias, y, NB, H, W, Cin, Cout, taps=9, mode=0, relu_mask=None):
+    _lib.check(_lib_().vtp_conv3x3(_p(x), _p(w), _p(bias), _p(y), _p(relu_mask), NB, H, W, Cin, Cout, taps, mode, _s()), "vtp_conv3x3")
+
+
+def lpips_unfold3(tok, img, out, n, H, W, shift, scale):
+    _lib.check(_lib_().vtp_lpips_unfold3(_p(tok), _p(img), _p(out), n, H, W, _f3(shift), _f3(scale), _s()), "vtp_lpips_unfold3")
+
+
+def lpips_fold3_bwd(dA, dt, n, H, W, scale):
+    _lib.check(_lib_().vtp_lpips_fold3_bwd(_p(dA), _p(dt), n, H, W, _f3(scale), _s()), "vtp_lpips_fold3_bwd")
+
+
+def maxpool2_fwd(x, y, NB, H, W, C):
+    _lib.check(_lib_().vtp_maxpool2_fwd(_p(x), _p(y), NB, H, W, C, _s()), "vtp_maxpool2_fwd")
+
+
+def maxpool2_bwd(Y, dP, tap, dY, NB, H, W, C):
+    _lib.check(_lib_().vtp_maxpool2_bwd(_p(Y), _p(dP), _p(tap), _p(dY), NB, H, W, C, _s()), "vtp_maxpool2_bwd")
+
+
+def lpips_tap(f0, f1, w, val, df0, n, H, W, C, gscale):
+    _lib.check(_lib_().vtp_lpips_tap(_p(f0), _p(f1), _p(w), _p(val), _p(df0), n, H, W, C, float(gscale), _s()), "vtp_lpips_tap")

@@ -91,8 +91,15 @@ class VTPTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
                  group=None, bucket_blocks: int = 3, use_graphs: bool = False, clip_weight: float = 1.0,
                  rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
-                 teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994):
+                 teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
+                 lpips=None, perceptual_weight: float = 0.0):
+        """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
+        reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
+        self.lpips, self.perceptual_weight = lpips, float(perceptual_weight)
+        if self.perceptual_weight > 0 and lpips is None:
+            raise ValueError("perceptual_weight > 0 needs an LPIPS module")
+        self.lpips_val = None  # per-image LPIPS of the last step (device f32 [B])
         self.store = model._engine()
         self.trunk, self.decoder = model._trunk, model._decoder
         self.text, self.clip = model._text, model._clip
@@ -256,6 +263,8 @@ class VTPTrainer:
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
         ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
+        if self.perceptual_weight > 0:  # perceptual term: adds its gradient w.r.t. the decoder output into dt
+            self.lpips_val = self.lpips.loss_and_grad(t, images, dt, self.perceptual_weight, B, H, W)
         if text is not None:
             d_xnf = self.trunk.d_xnf_buffer()[:B * N]  # rows of the lead item
             cw = self.clip.ws
