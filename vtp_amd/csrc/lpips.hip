@@ -156,67 +156,58 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const bf16* __restrict__
                                                         const float* __restrict__ w, float* __restrict__ val,
                                                         bf16* __restrict__ df0, int n, int H, int W, float gscale) {
   constexpr int C = LPP * 8, PPW = 64 / LPP;  // pixels per wave
+  __shared__ float red[4];
   const int W2 = W + 2, P = (H + 2) * W2;
   const int lane = threadIdx.x & 63, sub = lane % LPP;
-  const long pix = (blockIdx.x * 4L + (threadIdx.x >> 6)) * PPW + lane / LPP;
+  const int b = blockIdx.y;                     // one image per grid row: a block's partial sum goes to one val[b]
+  const f32x4 w0 = *(const f32x4*)(w + sub * 8), w1 = *(const f32x4*)(w + sub * 8 + 4);
+  float ww[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ww[e] = e < 4 ? w0[e] : w1[e - 4];
   float contrib = 0.f;
-  int b = 0;
-  const bool in_range = pix < (long)n * P;
-  if (in_range) {
-    b = (int)(pix / P);
-    const int r = (int)(pix % P), y = r / W2, x = r % W2;
-    const bool interior = y >= 1 && y <= H && x >= 1 && x <= W;
-    if (interior) {
-      const bf16x8 a = *(const bf16x8*)(f0 + pix * C + sub * 8), t = *(const bf16x8*)(f1 + pix * C + sub * 8);
-      const f32x4 w0 = *(const f32x4*)(w + sub * 8), w1 = *(const f32x4*)(w + sub * 8 + 4);
-      float fa[8], ft[8], ww[8];
-      float s0 = 0.f, s1 = 0.f;
+  for (int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP; r < P; r += gridDim.x * 4 * PPW) {
+    const int y = r / W2, x = r - y * W2;
+    if (y < 1 || y > H || x < 1 || x > W) continue;  // border rows: df0 stays zero (never written)
+    const long pix = (long)b * P + r;
+    const bf16x8 a = *(const bf16x8*)(f0 + pix * C + sub * 8), t = *(const bf16x8*)(f1 + pix * C + sub * 8);
+    float fa[8], ft[8];
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        fa[e] = bf2f(a[e]);
-        ft[e] = bf2f(t[e]);
-        ww[e] = e < 4 ? w0[e] : w1[e - 4];
-        s0 += fa[e] * fa[e];
-        s1 += ft[e] * ft[e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      fa[e] = bf2f(a[e]);
+      ft[e] = bf2f(t[e]);
+      s0 += fa[e] * fa[e];
+      s1 += ft[e] * ft[e];
+    }
 #pragma unroll
-      for (int o = 1; o < LPP; o <<= 1) {
-        s0 += __shfl_xor(s0, o, 64);
-        s1 += __shfl_xor(s1, o, 64);
-      }
-      const float r0 = sqrtf(s0), inv0 = 1.f / (r0 + 1e-10f), inv1 = 1.f / (sqrtf(s1) + 1e-10f);
-      float d = 0.f, tsum = 0.f, dn[8];
+    for (int o = 1; o < LPP; o <<= 1) {
+      s0 += __shfl_xor(s0, o, 64);
+      s1 += __shfl_xor(s1, o, 64);
+    }
+    const float r0 = sqrtf(s0), inv0 = 1.f / (r0 + 1e-10f), inv1 = 1.f / (sqrtf(s1) + 1e-10f);
+    float d = 0.f, tsum = 0.f, dn[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float df = fa[e] * inv0 - ft[e] * inv1;
-        d += ww[e] * df * df;
-        dn[e] = 2.f * gscale * ww[e] * df;
-        tsum += dn[e] * fa[e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      const float df = fa[e] * inv0 - ft[e] * inv1;
+      d += ww[e] * df * df;
+      dn[e] = 2.f * gscale * ww[e] * df;
+      tsum += dn[e] * fa[e];
+    }
+    contrib += d;  // every lane's share; summed over the block below
 #pragma unroll
-      for (int o = 1; o < LPP; o <<= 1) {
-        d += __shfl_xor(d, o, 64);
-        tsum += __shfl_xor(tsum, o, 64);
-      }
-      if (sub == 0) contrib = d / (float)(H * W);
-      if (df0) {
-        const float k2 = r0 > 0.f ? tsum * inv0 * inv0 / r0 : 0.f;
-        bf16x8 o;
+    for (int o = 1; o < LPP; o <<= 1) tsum += __shfl_xor(tsum, o, 64);
+    if (df0) {
+      const float k2 = r0 > 0.f ? tsum * inv0 * inv0 / r0 : 0.f;
+      bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(fa[e] > 0.f ? dn[e] * inv0 - fa[e] * k2 : 0.f);
-        *(bf16x8*)(df0 + pix * C + sub * 8) = o;
-      }
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(fa[e] > 0.f ? dn[e] * inv0 - fa[e] * k2 : 0.f);
+      *(bf16x8*)(df0 + pix * C + sub * 8) = o;
     }
   }
-  // per-image accumulation: all pixels of a wave belong to at most two images; reduce lanes that share b
-  const int b_first = __shfl(b, 0, 64);
-  float mine = (in_range && b == b_first) ? contrib : 0.f, other = (in_range && b != b_first) ? contrib : 0.f;
-  mine = wave_sum(mine);
-  other = wave_sum(other);
-  if (lane == 0) {
-    if (mine != 0.f) atomicAdd(val + b_first, mine);
-    if (other != 0.f) atomicAdd(val + b_first + 1, other);
-  }
+  // note: the shuffles above sit inside a loop whose trip count is uniform within each LPP-lane group (same pixel), and the
+  // `continue` is taken by whole groups, so the participating lanes of every shuffle agree
+  const float tot = block_sum<4>(contrib, red);
+  if (threadIdx.x == 0 && tot != 0.f) atomicAdd(val + b, tot / (float)(H * W));
 }
 
 }  // namespace vtp
@@ -261,11 +252,11 @@ extern "C" int vtp_lpips_tap(const void* f0, const void* f1, const float* w, flo
                              float gscale, void* stream) {
   VTP_REQUIRE(f0 && f1 && w && val && n > 0, "vtp_lpips_tap: bad argument");
   VTP_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, "vtp_lpips_tap: C must be 64, 128, 256 or 512 (VGG16 taps)");
-  const long pixels = (long)n * (H + 2) * (W + 2);
+  const long pixels = (long)(H + 2) * (W + 2);  // per image (grid.y = image)
   hipStream_t s = (hipStream_t)stream;
 #define VTP_TAP(L)                                                                                                          \
-  hipLaunchKernelGGL(lpips_tap_kernel<L>, dim3(cdiv(pixels, 4L * (64 / L))), dim3(256), 0, s, (const bf16*)f0, (const bf16*)f1, \
-                     w, val, (bf16*)df0, n, H, W, gscale)
+  hipLaunchKernelGGL(lpips_tap_kernel<L>, dim3(min(cdiv(pixels, 4L * (64 / L)), 96), n), dim3(256), 0, s, (const bf16*)f0,     \
+                     (const bf16*)f1, w, val, (bf16*)df0, n, H, W, gscale)
   switch (C) {
     case 64: VTP_TAP(8); break;
     case 128: VTP_TAP(16); break;

@@ -134,7 +134,6 @@ class VTPTrainer:
         self._bucket_plan = self._plan_buckets()
         # hyper-parameters live in device memory so that captured hipGraphs replay with per-step values
         self.hyper = torch.zeros(8, dtype=F32, device=st.device)
-        self._hyper_host = torch.zeros(8, dtype=F32).pin_memory()
         self.use_graphs = use_graphs
         self._graphs = {}
 
@@ -362,8 +361,9 @@ class VTPTrainer:
         b1, b2 = self.betas
         vals = [self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.step_no, (1.0 - b2 ** self.step_no) ** 0.5,
                 1.0 / self.world]
-        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        # a FRESH pinned staging tensor per step: the host may run several steps ahead of the GPU (graph replay), and the
+        # caching host allocator only recycles a pinned block after the async copy that reads it has completed
+        self.hyper.copy_(torch.tensor(vals, dtype=torch.float32).pin_memory(), non_blocking=True)
         if self.ssl_head is not None:
             self.momentum_dev.fill_(float(self.teacher_momentum))
 
