@@ -14,6 +14,7 @@
 // LDS images: row-major tiles use a 144-B row stride (16-B reads by 32 different rows hit 16 distinct slots);
 // transposed tiles use a 136-B row stride (8-B reads by 32 different rows cover all 64 banks once).
 #include "common.h"
+#include <cstdlib>
 #include "vtp_hip.h"
 
 namespace vtp {
@@ -407,6 +408,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+// short non-causal sequences: K/V (Q/dO) resident in LDS, one workgroup per (image, head) -- attention_resident.hip
+int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int N, int heads, long sb,
+                      long sn, long sbo, long sno, float scale, hipStream_t s);
+int attn_resident_bwd(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
+                      void* dq, void* dk, void* dv, int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale,
+                      hipStream_t s);
+static bool use_resident(int N, int causal) {
+  static const bool on = !(getenv("VTP_ATTN_RESIDENT") && atoi(getenv("VTP_ATTN_RESIDENT")) == 0);
+  return on && !causal && N <= 320;
+}
+
 }  // namespace vtp
 using namespace vtp;
 
@@ -424,6 +436,8 @@ extern "C" int vtp_attn_fwd(const void* q, const void* k, const void* v, void* o
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)o; a.lse = lse;
   a.B = B; a.N = N; a.heads = heads; a.sb = sb_qkv; a.sn = sn_qkv; a.sbo = sb_o; a.sno = sn_o; a.scale = scale;
+  if (use_resident(N, causal))
+    return attn_resident_fwd(q, k, v, o, lse, B, N, heads, sb_qkv, sn_qkv, sb_o, sn_o, scale, (hipStream_t)stream);
   dim3 grid(cdiv(N, 128), heads, B);
   if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -444,6 +458,8 @@ extern "C" int vtp_attn_bwd(const void* q, const void* k, const void* v, const v
   int dblocks = (int)((rows8 + 255) / 256);
   if (dblocks > 4096) dblocks = 4096;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(dblocks), dim3(256), 0, s, a);
+  if (use_resident(N, causal))
+    return attn_resident_bwd(q, k, v, d_o, lse, delta, dq, dk, dv, B, N, heads, sb_qkv, sn_qkv, sb_o, sn_o, scale, s);
   dim3 grid(cdiv(N, 128), heads, B);
   if (causal) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, s, a);
