@@ -172,6 +172,31 @@ def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottle
     return {"x_norm_clstoken": cls_t, "x_norm_patchtokens": patch_t, "x_prenorm": x}
 
 
+def intermediate_layers(sd, img, num_heads, n=1, reshape=False, return_class_token=False, norm=True, pre="trunk."):
+    """VTPModel.get_intermediate_layers_feature (modeling_vtp.py:214-240) = DinoVisionTransformer.get_intermediate_layers
+    (vision_transformer.py:266-318, no storage tokens, tied cls/patch norm)."""
+    x = patch_embed(img, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
+    B, hw, D = x.shape
+    H, W = img.shape[-2] // 16, img.shape[-1] // 16
+    cls = sd[pre + "cls_token"] + 0 * sd[pre + "mask_token"]
+    x = torch.cat([cls.expand(B, -1, -1), x], dim=1)
+    rope = rope_table(H, W, sd[pre + "rope_embed.periods"])
+    depth = _depth(sd, pre + "blocks.")
+    take = range(depth - n, depth) if isinstance(n, int) else n
+    outs = []
+    for i in range(depth):
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm")
+        if i in take:
+            outs.append(x)
+    if norm:
+        outs = [rmsnorm(o, sd[pre + "norm.weight"], 1e-5) for o in outs]
+    cls_t = [o[:, 0] for o in outs]
+    outs = [o[:, 1:] for o in outs]
+    if reshape:
+        outs = [o.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous() for o in outs]
+    return tuple(zip(outs, cls_t)) if return_class_token else tuple(outs)
+
+
 def reconstruction_latents(sd, img, num_heads) -> Tensor:
     """VTPModel.get_reconstruction_latents -- modeling_vtp.py:337-360,379-395."""
     out = trunk_forward(sd, img, num_heads, use_bottleneck=True)

@@ -69,3 +69,19 @@ def test_lpips():
     x0, x1 = torch.rand(2, 3, 32, 48, generator=g) * 2 - 1, torch.rand(2, 3, 32, 48, generator=g) * 2 - 1
     with torch.no_grad():
         torch.testing.assert_close(L.lpips(sd, x0, x1), m(x0, x1), rtol=1e-5, atol=1e-7)
+
+
+def test_intermediate_layers(ref_model):
+    sd = ref_model.state_dict()
+    img = torch.randn(2, 3, 96, 96)
+    with torch.no_grad():
+        for kw in (dict(n=2, reshape=False, return_class_token=True, norm=True), dict(n=[0, 2], reshape=True, return_class_token=False, norm=False)):
+            ref = ref_model.get_intermediate_layers_feature(img, **kw)
+            got = O.intermediate_layers(sd, img, 2, **kw)
+            assert len(ref) == len(got)
+            for r, g_ in zip(ref, got):
+                if kw["return_class_token"]:
+                    torch.testing.assert_close(g_[0], r[0], rtol=2e-4, atol=2e-5)
+                    torch.testing.assert_close(g_[1], r[1], rtol=2e-4, atol=2e-5)
+                else:
+                    torch.testing.assert_close(g_, r, rtol=2e-4, atol=2e-5)

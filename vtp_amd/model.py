@@ -302,6 +302,40 @@ class VTPModel(nn.Module):
         return {"cls_token": cls_t.contiguous(), "patch_tokens": patch_t.contiguous()}
 
     @torch.no_grad()
+    def get_intermediate_layers_feature(self, image: torch.Tensor, n=1, reshape: bool = False, return_class_token: bool = False,
+                                        norm: bool = True):
+        """modeling_vtp.py:214-240 -> DinoVisionTransformer.get_intermediate_layers (vision_transformer.py:266-318): outputs
+        of the last `n` blocks (or of the listed block indices), optionally through the trunk's final norm; patch tokens
+        [B, hw, D] (or [B, D, h, w] with reshape), each paired with its class token [B, D] when return_class_token."""
+        self._fresh()
+        img = self._img(image)
+        B, _, H, W = img.shape
+        h, w = H // 16, W // 16
+        tr = self._trunk
+        depth = tr.depth
+        take = list(range(depth - n, depth)) if isinstance(n, int) else [int(i) for i in n]
+        if not take or any(i < 0 or i >= depth for i in take):
+            raise AssertionError(f"only {len([i for i in take if 0 <= i < depth])} / {len(take)} blocks found")
+        tr.forward(img, train=True, tag="intermediate")  # train=True keeps every block's output buffer
+        c = tr.ctx()
+        M, D = c.M, tr.D
+        st = self._store
+        outs = []
+        for i in take:
+            x = c.ws.get(f"{i}.xout", (M, D), torch.float32)
+            if norm:
+                y = c.ws.get("inter.y", (M, D), torch.bfloat16)
+                stats = c.ws.get("inter.st", (M, 2), torch.float32)
+                ops.norm_fwd(x, st.p(tr.prefix + "norm.weight"), st.p(tr.prefix + "norm.bias") if tr.kind == ops.NORM_LN else None,
+                             y, stats, M, D, tr.eps, tr.kind)
+                x = y
+            x = x.float().view(B, h * w + 1, D)
+            cls_t, patch = x[:, 0].contiguous(), x[:, 1:]
+            patch = patch.reshape(B, h, w, D).permute(0, 3, 1, 2).contiguous() if reshape else patch.contiguous()
+            outs.append((patch, cls_t) if return_class_token else patch)
+        return tuple(outs)
+
+    @torch.no_grad()
     def get_clip_image_feature(self, image: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         """modeling_vtp.py:244-276."""
         if self.visual_proj is None:
