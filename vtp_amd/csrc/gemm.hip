@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   // walks a contiguous chunk of the tile list, n fastest: a chunk = a band of output rows x all weight panels.
   auto tile_origin = [&](int i, int& m0, int& n0) {
     int wg = blockIdx.x + i * G;
-    if (p.xcd_swizzle) {  // bijective on [0, ntiles)
+    if (p.xcd_swizzle & 1) {  // bijective on [0, ntiles)
       const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
       wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
     }
@@ -336,8 +336,153 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_nt_kernel(const Ge
   }
 
   // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
+  // bf16 outputs go through LDS so that the global stores are full 128/256-B row segments (16 B per lane, consecutive lanes
+  // = consecutive addresses) instead of 8-B pieces of 32 different rows per instruction: each wave transposes 32-row
+  // blocks of its sub-tile in a private region of the ring slot the last k-tile occupied (XOR-swizzled 16-B chunks).
+  bool staged_out = false;
+  if constexpr (EPI == EPI_BF16 && WTN >= 64 && !TRANS) {
+    if ((p.N & 7) == 0 && (p.xcd_swizzle & 2)) {
+      staged_out = true;
+      constexpr int RB = WTN * 2, CPR = RB / 16, REGION = STAGE_BYTES / NW;
+      static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
+      const int lb = (buf == 0 ? STAGES : buf) - 1;
+      __builtin_amdgcn_s_barrier();  // every wave finished reading the last k-tile
+      asm volatile("" ::: "memory");
+      char* reg = smem + lb * STAGE_BYTES + wave * REGION;
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = i * 32 + 8 * q + 4 * hi, n = n0 + wn * WTN + nl;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+            if (p.bias && n < p.N) v += *(const f32x4*)(p.bias + n);
+            *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
+          }
+#pragma unroll
+        for (int t = 0; t < 32 * CPR / 64; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+          const bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+          const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+          if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_SWIGLU && WTN >= 64 && !TRANS) {
+    // SwiGLU: the pre-activations x12 (interleaved gemm columns, bf16) and the hidden activations (WTN/2 columns) both leave
+    // through LDS; the activation itself is computed lane-locally first (quads (q, q+1) = (w1, w2) columns)
+    if ((p.xcd_swizzle & 2) && (p.N & 15) == 0) {
+      staged_out = true;
+      constexpr int RB = WTN * 2, CPR = RB / 16, RBH = WTN, CPRH = RBH / 16, REGION = STAGE_BYTES / NW;
+      static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
+      const int lb = (buf == 0 ? STAGES : buf) - 1;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      char* reg = smem + lb * STAGE_BYTES + wave * REGION;
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        bf16x4 hs[TN][2];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const int nl = i * 32 + 8 * q + 4 * hi, n1 = n0 + wn * WTN + nl;
+            f32x4 x1, x2, hsw;
+            const bool ok = n1 < p.N;
+            const f32x4 b1 = ok ? *(const f32x4*)(p.bias + n1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b2 = ok ? *(const f32x4*)(p.bias + n1 + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x1[e] = acc[i][j][4 * q + e] + b1[e];
+              x2[e] = acc[i][j][4 * q + 4 + e] + b2[e];
+            }
+            const bf16x4 x1b = __builtin_convertvector(x1, bf16x4), x2b = __builtin_convertvector(x2, bf16x4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hsw[e] = bf2f(f2bf(silu_f(bf2f(x1b[e])))) * bf2f(x2b[e]);
+            hs[i][q >> 1] = __builtin_convertvector(hsw, bf16x4);
+            if (p.C2) {
+              *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = x1b;
+              *(bf16x4*)(reg + r * RB + ((((nl >> 3) + 1) ^ (r & (CPR - 1))) << 4) + hi * 8) = x2b;
+            }
+          }
+        if (p.C2) {
+#pragma unroll
+          for (int t = 0; t < 32 * CPR / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+            const bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+            const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+            if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C2 + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc2 + n) = val;
+          }
+        }
+        // hidden: local column (2i + q/2)*8 + 4hi of a [32][WTN/2] block
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+            *(bf16x4*)(reg + r * RBH + ((((2 * i + h2)) ^ (r & (CPRH - 1))) << 4) + hi * 8) = hs[i][h2];
+#pragma unroll
+        for (int t = 0; t < 32 * CPRH / 64; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPRH, c = idx % CPRH;
+          const bf16x8 val = *(const bf16x8*)(reg + rr * RBH + ((c ^ (rr & (CPRH - 1))) << 4));
+          const int m = m0 + wm * WTM + j * 32 + rr, jh = ((n0 + wn * WTN) >> 1) + c * 8;
+          if (m < p.M && 2 * jh < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + jh) = val;
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_F32 && WTN >= 64 && !TRANS && (STAGE_BYTES / NW) / 4096 == 1) {  // measured: pays for the 8-wave
+    // 128x128 / 256x128 kernels (128-B staging rows); the 256-B-row variants of the 4-wave / 256x256 kernels lost 5-7 %
+    // fp32 residual epilogue: raw accumulators through LDS in column groups that fit the wave's region; bias / LayerScale /
+    // residual are applied after the read-back, where each lane owns 4 consecutive columns of one row (coalesced resid loads)
+    if ((p.xcd_swizzle & 2) && (p.N & 3) == 0) {
+      staged_out = true;
+      constexpr int REGION = STAGE_BYTES / NW;
+      constexpr int IG = (REGION / 4096 >= TN) ? TN : (REGION / 4096);   // 32-column blocks per pass (32 rows x 128 B each)
+      static_assert(IG >= 1 && TN % IG == 0, "bad column grouping");
+      constexpr int RB = IG * 128, CPR = RB / 16;
+      const int lb = (buf == 0 ? STAGES : buf) - 1;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      char* reg = smem + lb * STAGE_BYTES + wave * REGION;
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int ig = 0; ig < TN / IG; ++ig) {
+#pragma unroll
+          for (int ii = 0; ii < IG; ++ii)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[ig * IG + ii][j][4 * q + e] * p.alpha;
+              *(f32x4*)(reg + r * RB + (((ii * 8 + 2 * q + hi) ^ (r & (CPR - 1))) << 4)) = v;
+            }
+#pragma unroll
+          for (int t = 0; t < 32 * CPR / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+            f32x4 v = *(const f32x4*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+            const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + ig * IG * 32 + c * 4;
+            if (m < p.M && n < p.N) {
+              const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
+              if (p.bias) v += *(const f32x4*)(p.bias + n);
+              if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
+              if (p.resid) v += *(const f32x4*)(p.resid + off);
+              *(f32x4*)((float*)p.C + off) = v;
+            }
+          }
+        }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
+    if (staged_out) break;
     const int m = m0 + wm * WTM + j * 32 + (lane & 31);
     if (m >= p.M) continue;
     const int mc = remap_row(m, p.c_grp, p.c_pre);
@@ -484,7 +629,12 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
 // tile configurations (cfg id): 0 = 128x128 4 waves 2 stages | 1 = 128x128 4w 3 stages | 2 = 256x128 8w 2 stages |
 // 3 = 256x128 8w 3 stages | 4 = 256x256 8w 2 stages | 5 = 128x128 8w 2 stages | 6 = 128x128 4w 4 stages
 static int g_force_cfg = -1;
-static int g_xcd_swizzle = 1;
+static int g_xcd_swizzle = 3;  // bit 0: XCD-aware tile order | bit 1: LDS-staged full-line stores for bf16 outputs
+static int swz_flags() {
+  static const int v = getenv("VTP_GEMM_SWZ") ? atoi(getenv("VTP_GEMM_SWZ")) : -1;
+  return v >= 0 ? v : g_xcd_swizzle;
+}
+
 
 template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
@@ -521,7 +671,7 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   // big-M GEMMs (the row-concatenated list forward, M = 34k): 256x256 tiles halve the LDS / L2 traffic per flop; they
   // need >= 1.5 resident waves of tiles to beat the 128x128 kernels' finer quantisation (tools/gemm_bench.py 34144)
   static const int big_tiles = getenv("VTP_GEMM_BIG_TILES") ? atoi(getenv("VTP_GEMM_BIG_TILES")) : 384;
-  if (cdiv(M, 256) * cdiv(N, 256) >= big_tiles && (N >= 2304 || K >= 2048)) return 4;
+  if (cdiv(M, 256) * cdiv(N, 256) >= big_tiles && (N >= 2304 || K >= (epilogue == VTP_EPI_F32 ? 4096 : 2048))) return 4;
   static const int pipe_min_k = getenv("VTP_GEMM_PIPE_MINK") ? atoi(getenv("VTP_GEMM_PIPE_MINK")) : 4096;
   if (K >= pipe_min_k) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
@@ -553,7 +703,7 @@ extern "C" int vtp_conv3x3(const void* x, const void* w, const float* bias, void
   a.M = NB * (H + 2) * (W + 2); a.N = Cout; a.K = taps * Cin;
   a.lda = Cin; a.ldb = taps * Cin; a.ldc = Cout; a.ldc2 = Cout; a.alpha = 1.f;
   a.k_split = (a.K + 63) / 64 * 64;
-  a.xcd_swizzle = g_xcd_swizzle;
+  a.xcd_swizzle = swz_flags();
   a.conv_cin = taps == 9 ? Cin : 0; a.conv_w2 = W + 2; a.conv_h2 = H + 2; a.conv_p = (H + 2) * (W + 2);
   hipStream_t s = (hipStream_t)stream;
   return mode == 0 ? launch_conv<EPI_CONV_RELU>(a, s) : launch_conv<EPI_CONV_MASK>(a, s);
@@ -588,7 +738,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = alpha;
   a.b_grp = 0; a.b_pre = 0;
-  a.xcd_swizzle = g_xcd_swizzle;
+  a.xcd_swizzle = swz_flags();
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
@@ -624,7 +774,7 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = nullptr; a.bias = nullptr; a.gamma = nullptr; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.b_grp = b_grp; a.b_pre = b_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = 1.f;
-  a.xcd_swizzle = g_xcd_swizzle;
+  a.xcd_swizzle = swz_flags();
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
