@@ -238,10 +238,12 @@ WGRAD_TN = _os.environ.get("VTP_WGRAD", "tn") != "transpose"
 
 
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
-    """Split-K factor for a wgrad GEMM (output [n_rows, n_cols], reduction over k tokens): enough workgroups to fill
-    256 CUs (~384 tiles), each slice keeping >= 8 k-tiles."""
+    """Split-K factor for a wgrad GEMM (output [n_rows, n_cols], reduction over k tokens): the largest factor whose
+    tiles x splits workgroups still fit ONE resident wave of the 8-wave 128x128 kernel (256 CUs x 2 workgroups) -- a second,
+    partial round costs more than the shorter slices gain (tools/gemm_tn_bench.py: 768x2048 at 34k tokens, 5 splits = 480
+    workgroups 700 TF/s, 4 splits 604, 8 splits 646) -- with every slice keeping >= 8 k-tiles."""
     tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
-    return int(max(1, min(round(384 / tiles), k // 512, 16)))
+    return int(max(1, min(512 // tiles, k // 512, 16)))
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
