@@ -7,8 +7,9 @@
 
 One "step" = one full optimizer step of the hot path on one batch of synthetic 256x256 images already resident in HBM
 (forward, loss, backward, gradient all-reduce, fused AdamW, bf16 weight refresh).  Default workload: VTP-Base f16d64,
-32 images per GPU (BASELINE config 3's per-GPU shard; weak scaling), reconstruction (L1) objective -- the part of the
-config-3 step that is built so far (config.workload says exactly what ran).  Rank 0 prints ONE JSON line.
+32 images per GPU (BASELINE config 3's per-GPU shard; weak scaling), all three objectives: reconstruction (L1; LPIPS with
+--perceptual-weight), contrastive (InfoNCE with feature all-gather) and self-supervised (DINO + iBOT, EMA teacher);
+config.workload says exactly what ran.  Rank 0 prints ONE JSON line.
 
 Also reported on the same line:
   roofline     -- the dominant kernel (gemm_nt bf16 MFMA GEMM): algorithmic FLOPs (2*M*N*K per launch) / average launch
@@ -146,40 +147,63 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # VTP_BENCH_BACKEND=gloo + VTP_BENCH_SHARE_GPU=1: control-flow rehearsal of the N > 1 path on a one-GPU box (all ranks on
+    # device 0, gloo collectives); never used for reported numbers -- config.parallelism records it
+    backend = os.environ.get("VTP_BENCH_BACKEND", "nccl")
+    if os.environ.get("VTP_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vtp_amd import VTP, VTPConfig, VTPModel, VTPTrainer, ops
     cfg_kw, B, res, objectives = WORKLOADS[args.workload]
     clip, do_ssl = "clip" in objectives, "ssl" in objectives
     B = args.batch or B
-    torch.manual_seed(0)
-    model = (VTP(VTPConfig(**cfg_kw), dino_out_dim=args.prototypes) if do_ssl else VTPModel(VTPConfig(**cfg_kw))).to(dev)
-    lp = None
-    if args.perceptual_weight > 0:
-        from vtp_amd import LPIPS
-        lp = LPIPS().reset_parameters(0).to(dev)
-    trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=not args.no_graphs, lpips=lp,
-                         perceptual_weight=args.perceptual_weight)
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
-    txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
-    ssl = None
-    if do_ssl:
-        gc, lc, masks = synthetic_ssl(B, res, dev, 777 + rank)
-        ssl = trainer.prepare_ssl(gc, lc, masks)
+
+    def build_trainer(use_graphs: bool):
+        torch.manual_seed(0)
+        model = (VTP(VTPConfig(**cfg_kw), dino_out_dim=args.prototypes) if do_ssl else VTPModel(VTPConfig(**cfg_kw))).to(dev)
+        lp = None
+        if args.perceptual_weight > 0:
+            from vtp_amd import LPIPS
+            lp = LPIPS().reset_parameters(0).to(dev)
+        trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=use_graphs, lpips=lp,
+                             perceptual_weight=args.perceptual_weight)
+        txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
+        ssl = None
+        if do_ssl:
+            gc, lc, masks = synthetic_ssl(B, res, dev, 777 + rank)
+            ssl = trainer.prepare_ssl(gc, lc, masks)
+        return model, lp, trainer, txt, ssl
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(img, txt, ssl)
-    sync()
+    launch = "eager" if args.no_graphs else "hipGraph segments"
+    model, lp, trainer, txt, ssl = build_trainer(not args.no_graphs)
+    try:
+        for _ in range(args.warmup):
+            trainer.step(img, txt, ssl)
+        sync()
+    except RuntimeError as e:  # a capture problem must not cost the measurement: same step, eager launches
+        if args.no_graphs:
+            raise
+        print(f"[bench] hipGraph path failed ({str(e)[:200]}); falling back to eager launches", file=sys.stderr, flush=True)
+        launch = "eager (hipGraph capture failed on this configuration)"
+        model, lp, trainer, txt, ssl = build_trainer(False)
+        for _ in range(args.warmup):
+            trainer.step(img, txt, ssl)
+        sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, closs = trainer.step(img, txt, ssl)
@@ -194,33 +218,34 @@ def main():
     # ---- dominant-kernel roofline: one instrumented step, HIP events (recorded on the launch stream) around every launch of
     # the MFMA GEMM family -- gemm_nt (forward / dgrad) and gemm_tn (wgrad) are the same kernel template (rank 0)
     roof = None
+    recs = []
+    import vtp_amd.engine as eng
+    orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn
+
+    def timed(fn):
+        def run(a, b, c, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(a, b, c, **kw)
+            e1.record()
+            M = kw["M"] if kw.get("M") is not None else a.shape[0]
+            K = kw["K"] if kw.get("K") is not None else a.shape[1]
+            N = kw["N"] if kw.get("N") is not None else b.shape[0]
+            recs.append((2.0 * M * N * K, e0, e1))
+        return run
+
     if rank == 0:
-        recs = []
-        import vtp_amd.engine as eng
-        orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn
-
-        def timed(fn):
-            def run(a, b, c, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn(a, b, c, **kw)
-                e1.record()
-                M = kw["M"] if kw.get("M") is not None else a.shape[0]
-                K = kw["K"] if kw.get("K") is not None else a.shape[1]
-                N = kw["N"] if kw.get("N") is not None else b.shape[0]
-                recs.append((2.0 * M * N * K, e0, e1))
-            return run
-
         ops.gemm_nt, ops.gemm_tn = timed(orig_nt), timed(orig_tn)
-        trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
-        overlap_was = eng.OVERLAP.enabled
-        eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
-        try:
-            trainer.step(img, txt, ssl)
-            torch.cuda.synchronize()
-        finally:
-            ops.gemm_nt, ops.gemm_tn = orig_nt, orig_tn
-            eng.OVERLAP.enabled = overlap_was
+    trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
+    overlap_was = eng.OVERLAP.enabled
+    eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
+    try:
+        trainer.step(img, txt, ssl)  # every rank takes the step (it contains the collectives); rank 0 times its GEMMs
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt, ops.gemm_tn = orig_nt, orig_tn
+        eng.OVERLAP.enabled = overlap_was
+    if rank == 0:
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12
@@ -289,7 +314,7 @@ def main():
                                f"{B} img/GPU @ {res}x{res}{', 77-token synthetic captions' if clip else ''}, random-init weights; "
                                "rec and clip share one trunk pass (identical activations at drop rate 0); "
                                + ("LPIPS perceptual term included" if lp is not None else "LPIPS term not included (--perceptual-weight)"),
-                   "launch": "eager" if args.no_graphs else "hipGraph segments", "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}",
+                   "launch": launch, "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}" + ("" if backend == "nccl" else f" ({backend} rehearsal, shared GPU)"),
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
         "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info,

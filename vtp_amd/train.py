@@ -442,7 +442,8 @@ class VTPTrainer:
             while not done:
                 g = torch.cuda.CUDAGraph()
                 ev = None
-                with torch.cuda.graph(g, pool=pool):
+                # thread_local capture mode: the RCCL watchdog thread keeps querying events while this thread captures
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     try:
                         ev = next(gen)
                     except StopIteration:
