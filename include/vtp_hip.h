@@ -63,11 +63,12 @@ int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc
  * kind 0 = RMSNorm (normalization.py:17-22, eps 1e-5, no bias), 1 = LayerNorm (vision_transformer.py:30-34
  * eps 1e-6 decoder; normalization.py:25-31 text).  x f32 [M, D] -> y bf16 [M, D]; stats f32 [M,2] = (mean, rstd).
  * bwd: dx f32 [M,D] = (dres ? dres : 0) + norm_bwd(dy bf16), optionally also written as bf16 (dx_bf16, the A operand
- * of the next dgrad GEMM); dw/db f32 [D] are ACCUMULATED (+=) atomically. */
+ * of the next dgrad GEMM); dw/db f32 [D] are ACCUMULATED (+=) atomically.  dx_colsum (optional, f32 [D], accumulated):
+ * column sums of dx_bf16 = the bias gradient of the linear layer that receives dx_bf16 as its dy (no separate pass). */
 int vtp_norm_fwd(const float* x, const float* w, const float* b, void* y, float* stats, int M, int D, float eps,
                  int kind, void* stream);
 int vtp_norm_bwd(const void* dy, const float* x, const float* w, const float* stats, const float* dres, float* dx,
-                 void* dx_bf16, float* dw, float* db, int M, int D, int kind, void* stream);
+                 void* dx_bf16, float* dw, float* db, float* dx_colsum, int M, int D, int kind, void* stream);
 
 /* ---- RoPE (attention.py:12-23,70-89) ----------------------------------------------------------
  * In place on the q and k thirds of a packed qkv bf16 [B*N, 3*D] buffer (head h at column h*64 of each third).

@@ -169,7 +169,10 @@ def test_norm_fwd_bwd(kind, D):
     dxb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
     dw = torch.zeros(D, device=DEV)
     db = torch.zeros(D, device=DEV) if kind else None
-    o.norm_bwd(dy, x, w, st, dres, dx, dxb, dw, db, M, D, kind)
+    dxs = torch.full((D,), 3.0, device=DEV)  # accumulated into: column sums of the bf16 output (the next linear's bias grad)
+    o.norm_bwd(dy, x, w, st, dres, dx, dxb, dw, db, M, D, kind, dx_colsum=dxs)
+    cs = dxb.float().sum(0) + 3.0
+    assert float((dxs - cs).abs().max()) <= 1e-4 * float(dxb.float().abs().sum(0).max()) + 1e-4, "norm_bwd dx_colsum"
     check(dx, xr.grad + dres, "norm_bwd dx", bf16_out=False, scale=2e-5)
     check(dxb, bf(xr.grad + dres), "norm_bwd dx bf16")
     check(dw, wr.grad, "norm_bwd dw", bf16_out=False, scale=1e-4)

@@ -13,7 +13,7 @@ _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "vtp_gemm_nt": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vtp_norm_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
-    "vtp_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],  # dy x w stats dres dx dxb dw db M D kind stream
+    "vtp_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],  # dy x w stats dres dx dxb dw db dxsum M D kind stream
     "vtp_rope_qk": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vtp_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],
     "vtp_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],

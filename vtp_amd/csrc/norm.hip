@@ -77,17 +77,21 @@ template <int KIND, int NC>
 __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ stats,
                                                        const float* __restrict__ dres, float* __restrict__ dx,
-                                                       bf16* __restrict__ dxb, float* __restrict__ dw, float* __restrict__ db, int M, int D) {
+                                                       bf16* __restrict__ dxb, float* __restrict__ dw, float* __restrict__ db,
+                                                       float* __restrict__ dxsum, int M, int D) {
   constexpr int R = NC <= 3 ? 2 : 1;  // rows in flight per wave: the x / dy loads of all R rows are issued before the first reduction
   const int lane = threadIdx.x & 63;
   const int wv_id = threadIdx.x >> 6;
-  f32x4 wreg[NC], dwacc[NC], dbacc[NC];
+  // dbacc: LayerNorm bias gradient (column sums of dy) -- or, for RMSNorm (no bias), the column sums of the bf16 OUTPUT
+  // (dxsum): the bias gradient of the linear layer whose dy this output is, so that layer needs no separate colsum pass
+  f32x4 wreg[NC], dwacc[NC], dbacc[NC], dsacc[KIND == 1 ? NC : 1];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int col = (c * 64 + lane) * 4;
     if (col < D) wreg[c] = *(const f32x4*)(w + col);
     dwacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dbacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (KIND == 1) dsacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int row0 = (blockIdx.x * 4 + wv_id) * R; row0 < M; row0 += gridDim.x * 4 * R) {
     f32x4 xv[R][NC];
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict
             s1 += g[c][e];
             s2 += g[c][e] * xh[c][e];
             dwacc[c][e] += gyf[e] * xh[c][e];
-            dbacc[c][e] += gyf[e];
+            if (KIND == 1) dbacc[c][e] += gyf[e];
           }
         }
       }
@@ -140,23 +144,34 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict
           for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (g[c][e] - s1 - xh[c][e] * s2);
           if (dres) o += *(const f32x4*)(dres + (size_t)row * D + col);
           *(f32x4*)(dx + (size_t)row * D + col) = o;
-          if (dxb) *(bf16x4*)(dxb + (size_t)row * D + col) = __builtin_convertvector(o, bf16x4);
+          if (dxb) {
+            const bf16x4 ob = __builtin_convertvector(o, bf16x4);
+            *(bf16x4*)(dxb + (size_t)row * D + col) = ob;
+            if (dxsum) {
+              const f32x4 of = __builtin_convertvector(ob, f32x4);
+              if (KIND == 1) dsacc[c] += of; else dbacc[c] += of;
+            }
+          }
         }
       }
     }
   }
   // reduce dw/db over the 4 waves of the block through LDS, then one atomic per column
   __shared__ float red[4][NC * 256];
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && (KIND == 0 || db == nullptr)) break;
+  for (int pass = 0; pass < 3; ++pass) {
+    // pass 0: dw | pass 1: db (LayerNorm) | pass 2: dxsum (RMSNorm keeps it in dbacc, LayerNorm in dsacc)
     if (pass == 0 && dw == nullptr) continue;
+    if (pass == 1 && (KIND == 0 || db == nullptr)) continue;
+    if (pass == 2 && (dxsum == nullptr || dxb == nullptr)) continue;
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[wv_id][(c * 64 + lane) * 4 + e] = pass == 0 ? dwacc[c][e] : dbacc[c][e];
+      for (int e = 0; e < 4; ++e)
+        red[wv_id][(c * 64 + lane) * 4 + e] =
+            pass == 0 ? dwacc[c][e] : (pass == 1 ? dbacc[c][e] : (KIND == 1 ? dsacc[KIND == 1 ? c : 0][e] : dbacc[c][e]));
     __syncthreads();
-    float* out = pass == 0 ? dw : db;
+    float* out = pass == 0 ? dw : (pass == 1 ? db : dxsum);
     for (int col = threadIdx.x; col < D; col += 256)
       unsafeAtomicAdd(out + col, red[0][col] + red[1][col] + red[2][col] + red[3][col]);
   }
@@ -189,16 +204,18 @@ extern "C" int vtp_norm_fwd(const float* x, const float* w, const float* b, void
 }
 
 extern "C" int vtp_norm_bwd(const void* dy, const float* x, const float* w, const float* stats, const float* dres,
-                            float* dx, void* dx_bf16, float* dw, float* db, int M, int D, int kind, void* stream) {
+                            float* dx, void* dx_bf16, float* dw, float* db, float* dx_colsum, int M, int D, int kind,
+                            void* stream) {
   VTP_REQUIRE(dy && x && w && stats && dx, "vtp_norm_bwd: null pointer");
+  VTP_REQUIRE(!dx_colsum || dx_bf16, "vtp_norm_bwd: dx_colsum sums the bf16 output and needs dx_bf16");
   VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
   VTP_REQUIRE(kind == 0 || kind == 1, "vtp_norm_bwd: kind must be 0 or 1");
   int blocks = cdiv(M, D <= 768 ? 8 : 4);
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);
   if (kind == 0)
-    NORM_DISPATCH(norm_bwd_kernel, 0, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, M, D);
+    NORM_DISPATCH(norm_bwd_kernel, 0, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, dx_colsum, M, D);
   else
-    NORM_DISPATCH(norm_bwd_kernel, 1, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, M, D);
+    NORM_DISPATCH(norm_bwd_kernel, 1, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, dx_colsum, M, D);
   return check_launch("norm_bwd");
 }

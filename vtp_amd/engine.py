@@ -247,7 +247,8 @@ def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
-               x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0):
+               x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0,
+               bias_grad_done: bool = False):
     """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
     column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
@@ -258,6 +259,8 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         gw = L.gw if gw is None else gw
         gb = L.gb if gb is None else gb
         wT = L.wT if wT is None else wT
+    if bias_grad_done:  # the kernel that produced dy_b already accumulated its column sums into the bias gradient
+        gb = None
     Mp = pad8(M)
     c_remap = (-1, swiglu_h) if swiglu_h else (0, 0)
     S = ops.gemm_splits(Mp, _wgrad_splits(N, K, Mp))
@@ -414,9 +417,12 @@ class Stack:
         return x
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
-    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None, segs=None):
+    def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None, segs=None,
+                 dy_colsum_done: bool = False):
         """Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
-        gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input."""
+        gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input.
+        dy_colsum_done: the caller's norm backward already summed dy_b's columns into the last block's w3 bias gradient
+        (self.blocks[-1].w3.gb as its dx_colsum)."""
         D, H, heads = self.D, self.H, self.heads
         segs = [(B, N, rope)] if segs is None else segs
         M = sum(b * n for b, n, _ in segs)
@@ -438,7 +444,7 @@ class Stack:
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
             # ---- FFN: x_out = x_mid + w3(act(...))
-            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh)
+            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh, bias_grad_done=dy_colsum_done or i < self.depth - 1)
             if vit:
                 ops.swiglu_bwd(dh, pre, dpre, M, H)
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
@@ -446,9 +452,11 @@ class Stack:
             else:
                 ops.gelu_bwd(dh, pre, dpre, M * H)
                 linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn)
-            ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind)
+            # the norm backward kernels also sum the columns of their bf16 output = the bias gradient of the linear layer that
+            # takes it as dy (proj here; the previous block's w3 below)
+            ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind, dx_colsum=b.proj.gb)
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
-            linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o)
+            linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o, bias_grad_done=b.proj.gb is not None)
             for r0, Bs, Ns, rp in self._rows(segs):
                 r1 = r0 + Bs * Ns
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
@@ -457,7 +465,8 @@ class Stack:
                 if rp is not None:
                     ops.rope_qk(dq_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens, inverse=True)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
-            ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind)
+            ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind,
+                         dx_colsum=self.blocks[i - 1].w3.gb if i > 0 else None)
             dy, dy_b = dxo, dxo_b
             OVERLAP.join()
             yield ("block", i)
@@ -594,10 +603,12 @@ class TrunkEngine:
         dx = ws.get("b.dxt", (M, D), F32)
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, c.xl, st.p(self.prefix + "norm.weight"), c.stf, None, dx, dx_b, st.g(self.prefix + "norm.weight"),
-                     st.g(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
+                     st.g(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind,
+                     dx_colsum=self.stack.blocks[-1].w3.gb)
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs)
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs,
+                                                    dy_colsum_done=True)
         for g in c.segs:
             d_s, d_sb = dx0[g.row0:g.row0 + g.B * g.N], dx0_b[g.row0:g.row0 + g.B * g.N]
             if g.masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
@@ -670,10 +681,11 @@ class DecoderEngine:
         dx = ws.get("b.dxt", (M, D), F32)
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, xl, st.p("pixel_decoder.norm.weight"), stf, None, dx, dx_b, st.g("pixel_decoder.norm.weight"),
-                     st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind)
+                     st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind,
+                     dx_colsum=self.stack.blocks[-1].w3.gb)
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, stack_saved)
+        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, stack_saved, dy_colsum_done=True)
         d_lat = ws.get("b.d_lat", (M, self.cin), BF)
         linear_bwd(ws, "pin", self.pin, dx0_b, lat, M, d_lat)
         OVERLAP.join()

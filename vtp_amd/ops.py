@@ -46,9 +46,9 @@ def norm_fwd(x, w, b, y, stats, M, D, eps, kind):
     _lib.check(_lib_().vtp_norm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, D, eps, kind, _s()), "vtp_norm_fwd")
 
 
-def norm_bwd(dy, x, w, stats, dres, dx, dxb, dw, db, M, D, kind):
-    _lib.check(_lib_().vtp_norm_bwd(_p(dy), _p(x), _p(w), _p(stats), _p(dres), _p(dx), _p(dxb), _p(dw), _p(db), M, D, kind,
-                                    _s()), "vtp_norm_bwd")
+def norm_bwd(dy, x, w, stats, dres, dx, dxb, dw, db, M, D, kind, dx_colsum=None):
+    _lib.check(_lib_().vtp_norm_bwd(_p(dy), _p(x), _p(w), _p(stats), _p(dres), _p(dx), _p(dxb), _p(dw), _p(db), _p(dx_colsum),
+                                    M, D, kind, _s()), "vtp_norm_bwd")
 
 
 def rope_qk(qkv, sin, cos, B, N, heads, prefix, inverse=False):

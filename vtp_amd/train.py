@@ -398,6 +398,32 @@ class VTPTrainer:
     def step_rec(self, images: torch.Tensor) -> torch.Tensor:
         return self.step(images, None)[0]
 
+    # ---- training-state checkpoint: the model's own state_dict (student, teacher, heads) travels in the
+    # reference's HF layout; this is the rest of the state a resumed run needs
+    def state_dict(self) -> dict:
+        """Optimizer moments (as name -> tensor, the same keys as model.state_dict()), step counter and SSL centres."""
+        st = self.store
+        sd = {"step": self.step_no, "exp_avg": {}, "exp_avg_sq": {}}
+        for name, (o, k) in st.offsets.items():
+            sd["exp_avg"][name] = self.m[o:o + k].detach().clone().view(st.params[name].shape).cpu()
+            sd["exp_avg_sq"][name] = self.v[o:o + k].detach().clone().view(st.params[name].shape).cpu()
+        if self.ssl_head is not None:
+            sd["center_dino"], sd["center_ibot"] = self.center_dino.cpu().clone(), self.center_ibot.cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd: dict):
+        st = self.store
+        missing = [n for n in st.offsets if n not in sd["exp_avg"] or n not in sd["exp_avg_sq"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks {len(missing)} parameters, e.g. {missing[:3]}")
+        self.step_no = int(sd["step"])
+        for name, (o, k) in st.offsets.items():
+            self.m[o:o + k].copy_(sd["exp_avg"][name].reshape(-1))
+            self.v[o:o + k].copy_(sd["exp_avg_sq"][name].reshape(-1))
+        if self.ssl_head is not None and "center_dino" in sd:
+            self.center_dino.copy_(sd["center_dino"])
+            self.center_ibot.copy_(sd["center_ibot"])
+
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
     def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
         skey = None

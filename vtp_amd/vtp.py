@@ -18,7 +18,7 @@ from torch import nn
 
 from . import ops
 from .config import VTPConfig
-from .engine import BF, F32, TrunkEngine
+from .engine import BF, F32, OVERLAP, TrunkEngine
 from .model import VTPModel, _holder, _param
 from .ssl_engine import DinoHeadEngine, build_ssl_indices
 
@@ -142,12 +142,23 @@ def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_pla
     Tt = B2 + Tm
     if masks_u8.dtype != torch.uint8:
         masks_u8 = masks_u8.to(torch.uint8).contiguous()
-    # ---- teacher (EMA weights, clean input, no gradient): vtp.py:410-450
-    xnf_t = model._t_trunk.forward(global_crops, train=False, tag="teacher")
+    # ---- teacher (EMA weights, clean input, no gradient): vtp.py:410-450.  Independent of the student pass until the loss:
+    # it runs on the side stream and fills the CUs the student's GEMM tails leave idle (joined before the logits are used)
     ws = model._head.workspace(Ts, "ssl_io")
     Xt = ws.get("Xt", (Tt, D), BF)
-    ops.gather_token_rows(xnf_t, idx["teacher_src"], Xt, Tt, D)
-    t_logits, _ = model._t_head.forward(Xt, Tt, tag="teacher")
+
+    def teacher():
+        xnf_t = model._t_trunk.forward(global_crops, train=False, tag="teacher")
+        ops.gather_token_rows(xnf_t, idx["teacher_src"], Xt, Tt, D)
+        return model._t_head.forward(Xt, Tt, tag="teacher")[0]
+
+    if OVERLAP.enabled:
+        OVERLAP.join()
+        OVERLAP.fork()
+        with torch.cuda.stream(OVERLAP.side):
+            t_logits = teacher()
+    else:
+        t_logits = teacher()
     # ---- student: masked global crops + local crops through the SAME trunk weights (vtp.py:452-484)
     items = ([(lead_images, None)] if lead_images is not None else []) + [(global_crops, masks_u8), (local_crops, None)]
     xnf = model._trunk.forward_list(items, train=train, tag="ssl")
@@ -158,5 +169,6 @@ def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_pla
     ops.gather_token_rows(xnf[seg_l.row0:], idx["student_local_src"], Xs, nl, D)
     ops.gather_token_rows(xnf[seg_g.row0:], idx["student_global_src"], Xs[nl:], Ts - nl, D)
     s_logits, head_ctx = model._head.forward(Xs, Ts, tag="student")
+    OVERLAP.join()  # teacher logits complete
     return dict(teacher_logits=t_logits, student_logits=s_logits, head_ctx=head_ctx, ctx=ctx, xnf=xnf, idx=idx,
                 Xs=Xs, student_global_cls=Xs[nl:nl + B2], Tt=Tt, Ts=Ts, Tm=Tm, nl=nl, B2=B2, N=N, ws=ws)
