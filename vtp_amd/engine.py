@@ -209,19 +209,25 @@ def _env_flag(name: str, default: str = "1") -> bool:
 
 
 class Overlap:
-    """Side HIP stream for the weight-gradient branch of every linear backward: dW (transposes + split-K GEMM + slab
-    reduce) is independent of dX, so it runs concurrently with the dgrad GEMM and fills the CUs that the other kernel's
-    tail leaves idle.  fork/join are event waits (captured as parallel hipGraph branches under stream capture)."""
+    """Side HIP streams for work that is independent of the main stream's next kernels and fills the CUs their tails leave
+    idle: the weight-gradient branch of every linear backward (column sums + split-K TN GEMM + slab reduce run concurrently
+    with the dgrad GEMM), the EMA teacher's forward, and -- on lane 1 -- the text tower, which the trainer issues on its own
+    stream with its own wgrad side stream.  fork/join are event waits (parallel hipGraph branches under stream capture)."""
 
-    enabled = _env_flag("VTP_OVERLAP")  # VTP_OVERLAP=0: run the dW branch in-line (clean per-kernel profiles)
+    enabled = _env_flag("VTP_OVERLAP")  # VTP_OVERLAP=0: everything in-line on one stream (clean per-kernel profiles)
 
     def __init__(self):
-        self.side = None
+        self._sides = {}
+        self._lane = 0
+
+    @property
+    def side(self):
+        return self._sides.get(self._lane)
 
     def _side(self):
-        if self.side is None:
-            self.side = torch.cuda.Stream()
-        return self.side
+        if self._lane not in self._sides:
+            self._sides[self._lane] = torch.cuda.Stream()
+        return self._sides[self._lane]
 
     def fork(self):
         self._side().wait_stream(torch.cuda.current_stream())
@@ -229,6 +235,19 @@ class Overlap:
     def join(self):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+
+    def lane(self, k: int):
+        """context: fork / join / side refer to side stream k while a second tower is being issued on another stream"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._lane = self._lane, k
+            try:
+                yield
+            finally:
+                self._lane = prev
+        return ctx()
 
 
 OVERLAP = Overlap()

@@ -100,6 +100,7 @@ class VTPTrainer:
         if self.perceptual_weight > 0 and lpips is None:
             raise ValueError("perceptual_weight > 0 needs an LPIPS module")
         self.lpips_val = None  # per-image LPIPS of the last step (device f32 [B])
+        self._text_stream = None
         self.store = model._engine()
         self.trunk, self.decoder = model._trunk, model._decoder
         self.text, self.clip = model._text, model._clip
@@ -258,19 +259,37 @@ class VTPTrainer:
             xnf = (yield from self._ssl_gen(ssl, lead_images=images))["xnf"][:B * N]  # rows of the lead item
         else:
             xnf = self.trunk.forward(images, train=True)
+        # the text tower's GEMMs are small (M = 77 B rows): it is issued on its own stream (with its own wgrad side stream,
+        # OVERLAP lane 1) so that it runs concurrently with the decoder forward / the first decoder-backward blocks
+        import os as _os
+        par_text = text is not None and OVERLAP.enabled and _os.environ.get("VTP_TEXT_STREAM", "1") != "0"
+        par_fwd = par_bwd = par_text
+        main = torch.cuda.current_stream()
+        if par_text:
+            if self._text_stream is None:
+                self._text_stream = torch.cuda.Stream()
+            T = self._text_stream
+        if par_fwd:
+            T.wait_stream(main)
+            with torch.cuda.stream(T), OVERLAP.lane(1):
+                f_txt = self.text.forward(text, train=True)
         lat = self.trunk.latents()
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
         ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
         if self.perceptual_weight > 0:  # perceptual term: adds its gradient w.r.t. the decoder output into dt
             self.lpips_val = self.lpips.loss_and_grad(t, images, dt, self.perceptual_weight, B, H, W)
+        held = None  # bucket keys whose gradients are being produced on the text stream
         if text is not None:
             d_xnf = self.trunk.d_xnf_buffer()[:B * N]  # rows of the lead item
             cw = self.clip.ws
             Dt = self.clip.Dt
             f_img = self.clip.image_features(xnf, B, N)
             img_n, inv_i = self.clip.normalize(f_img, "img")
-            f_txt = self.text.forward(text, train=True)
+            if par_fwd:
+                main.wait_stream(T)
+            else:
+                f_txt = self.text.forward(text, train=True)
             txt_n, inv_t = self.clip.normalize(f_txt, "txt")
             Bg = B * self.world
             if self.world > 1:
@@ -308,13 +327,50 @@ class VTPTrainer:
                 d_txt_l.mul_(self.clip_weight)
                 st.g("logit_scale").mul_(self.clip_weight)
             d_f_txt = self.clip.normalize_bwd(d_txt_l, txt_n, inv_t, "txt")
-            yield from self._tower_backward("text", self.text.backward(d_f_txt), self.text.depth)
-            yield ["text_head"]
+            if par_bwd:  # whole text backward on the text stream; its buckets are announced once it has been joined
+                T.wait_stream(main)
+                held = []
+                # wgrads in-line on the text stream: a side stream forked from an already forked stream (nested fork) crashes
+                # hipStreamEndCapture on ROCm 7.2, and the text stream as a whole already runs beside the main one
+                with torch.cuda.stream(T), OVERLAP.lane(1):
+                    was, OVERLAP.enabled = OVERLAP.enabled, False
+                    try:
+                        for ev in self._tower_backward("text", self.text.backward(d_f_txt), self.text.depth):
+                            held += ev
+                    finally:
+                        OVERLAP.enabled = was
+                held.append("text_head")
+            else:
+                yield from self._tower_backward("text", self.text.backward(d_f_txt), self.text.depth)
+                yield ["text_head"]
             d_f_img = self.clip.normalize_bwd(d_img_l, img_n, inv_i, "img")
             self.clip.image_backward(d_f_img, xnf, d_xnf, B, N)  # writes the cls rows of d_xnf
             OVERLAP.join()
-            yield ["clip_head"]
-        d_lat = yield from self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
+            if held is not None:
+                held.append("clip_head")
+            else:
+                yield ["clip_head"]
+        # decoder backward; while the text stream is busy its first event is held back (a yield ends a graph segment, and every
+        # forked stream must be joined before that) so the text backward overlaps the decoder tail + its first blocks
+        dec_gen = self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
+        d_lat, seen = None, 0
+        while True:
+            try:
+                ev = next(dec_gen)
+            except StopIteration as stop:
+                d_lat = stop.value
+                break
+            if held is not None:
+                if seen < 1:
+                    held += ev
+                    seen += 1
+                    continue
+                main.wait_stream(T)
+                ev, held = held + ev, None
+            yield ev
+        if held is not None:
+            main.wait_stream(T)
+            yield held
         yield ["dec_head"]
         yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
         yield ["trunk_head", "FINAL"]
