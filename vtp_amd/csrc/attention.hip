@@ -1,5 +1,7 @@
 // Flash-style fused attention for gfx950, head_dim = 64, bf16 in / fp32 accumulate  (replaces
 // F.scaled_dot_product_attention, attention.py:124, and nn.MultiheadAttention's core in the text tower).
+// This file: the TILED kernels (any N, causal or not: 1025-token sequences at 512^2, the causal 77-token text tower) and the
+// C entry points; short non-causal sequences dispatch to the LDS-resident kernels of attention_resident.hip.
 //
 // MFMA: v_mfma_f32_32x32x16_bf16.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 //
@@ -7,12 +9,12 @@
 // S^T): the online softmax is lane-local (16 registers + one cross-half exchange), and P^T in the accumulator
 // registers is directly the B operand of O^T = V^T P^T (register r = 8*ks + j is k-slot j of k-step ks for BOTH
 // operands, so the hardware's slot->k mapping cancels).  The A operand V^T (and K^T for dQ) must be contiguous
-// along keys: the [keys][64] tile is transposed while it is staged into LDS.
+// along keys: the [keys][64] tile is staged row-major and read with the LDS transpose read ds_read_b64_tr_b16.
 // The dK/dV pass uses the plain product S = Q K^T (one lane owns one key) so P and dS are B operands of
-// dV^T = dO^T P and dK^T = Q^T dS; Q^T / dO^T are transposed at staging.
+// dV^T = dO^T P and dK^T = Q^T dS; Q^T / dO^T come from transpose reads of the row-major tiles as well.
 //
-// LDS images: row-major tiles use a 144-B row stride (16-B reads by 32 different rows hit 16 distinct slots);
-// transposed tiles use a 136-B row stride (8-B reads by 32 different rows cover all 64 banks once).
+// LDS images: tiles read as rows (16-B fragments of 32 different rows) use a 144-B row stride (16 distinct slots);
+// tiles read transposed use a 192-B row stride (the 4 rows x 64 B of a half-wave land on disjoint bank quarters).
 #include "common.h"
 #include <cstdlib>
 #include "vtp_hip.h"
@@ -21,7 +23,6 @@ namespace vtp {
 
 constexpr int KT = 64;        // keys (or queries) per staged tile
 constexpr int RS = 72;        // row stride (elements) of row-major [64][64] tiles
-constexpr int TS = 68;        // row stride (elements) of transposed [64 d][64 seq] tiles (legacy scatter path)
 constexpr int RT = 96;        // row stride (elements) of row-major tiles that are read with ds_read_b64_tr_b16 (4 rows x 64 B
                               // of one half-wave land on 4 disjoint 16-dword bank ranges: 0, 48, 32, 16)
 constexpr float LOG2E = 1.4426950408889634f;
@@ -40,23 +41,6 @@ struct AttnArgs {
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// stage a [64 rows][64 d] bf16 tile (rows row0.., clamped to N-1) row-major and/or transposed into LDS
-template <bool ROWMAJ, bool TRANS>
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, long sn, int row0, int N, bf16* rm, bf16* tr) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = threadIdx.x + i * 256;
-    const int r = c >> 3, dc = (c & 7) * 8;
-    const int n = min(row0 + r, N - 1);
-    bf16x8 v = *(const bf16x8*)(base + (long)n * sn + dc);
-    if (ROWMAJ) *(bf16x8*)(rm + r * RS + dc) = v;
-    if (TRANS) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) tr[(dc + e) * TS + r] = v[e];
-    }
-  }
 }
 
 // stage a [64 rows][64 d] tile row-major into up to two LDS images with different row strides (16-B writes only)
@@ -89,13 +73,6 @@ __device__ __forceinline__ bf16x8 frag_trr(const bf16* tile, int dblk, int blk, 
 __device__ __forceinline__ bf16x8 frag_rm(const bf16* rm, int blk, int ks, int lane) {
   return *(const bf16x8*)(rm + (blk * 32 + (lane & 31)) * RS + ks * 16 + (lane >> 5) * 8);
 }
-// A-operand fragment from a transposed tile [64 d][seq]: lane row d = dblk*32 + (lane&31); k-slots are
-// seq = blk*32 + 16*ks + 4*hi + {0..3} and + 8 + {0..3}  (matches accumulator register order)
-__device__ __forceinline__ bf16x8 frag_tr(const bf16* tr, int dblk, int blk, int ks, int lane) {
-  const bf16* p = tr + (dblk * 32 + (lane & 31)) * TS + blk * 32 + ks * 16 + (lane >> 5) * 4;
-  return cat4(*(const bf16x4*)p, *(const bf16x4*)(p + 8));
-}
-
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
   bf16x8 r;
 #pragma unroll

@@ -16,6 +16,7 @@ SelfAttention.forward (attention.py:91-126) / SwiGLUFFN.forward (ffn.py:77-81), 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -199,13 +200,11 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
 
-import os as _os_mod
-
 BF, F32 = torch.bfloat16, torch.float32
 
 
 def _env_flag(name: str, default: str = "1") -> bool:
-    return _os_mod.environ.get(name, default) not in ("0", "false", "off")
+    return os.environ.get(name, default) not in ("0", "false", "off")
 
 
 class Overlap:
@@ -252,8 +251,7 @@ class Overlap:
 
 OVERLAP = Overlap()
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
-import os as _os
-WGRAD_TN = _os.environ.get("VTP_WGRAD", "tn") != "transpose"
+WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
 
 
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:

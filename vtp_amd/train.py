@@ -23,6 +23,7 @@ Objectives (OUR spec -- the reference defines no loss; parity unpinned):
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -261,8 +262,7 @@ class VTPTrainer:
             xnf = self.trunk.forward(images, train=True)
         # the text tower's GEMMs are small (M = 77 B rows): it is issued on its own stream (with its own wgrad side stream,
         # OVERLAP lane 1) so that it runs concurrently with the decoder forward / the first decoder-backward blocks
-        import os as _os
-        par_text = text is not None and OVERLAP.enabled and _os.environ.get("VTP_TEXT_STREAM", "1") != "0"
+        par_text = text is not None and OVERLAP.enabled and os.environ.get("VTP_TEXT_STREAM", "1") != "0"
         par_fwd = par_bwd = par_text
         main = torch.cuda.current_stream()
         if par_text:
