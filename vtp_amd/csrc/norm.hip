@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict
     if (KIND == 1) dsacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int row0 = (blockIdx.x * 4 + wv_id) * R; row0 < M; row0 += gridDim.x * 4 * R) {
-    f32x4 xv[R][NC];
+    // narrow rows (NC <= 3): the residual-gradient row is fetched together with x and dy, ahead of the two wave
+    // reductions (2 waves/SIMD leave 256 VGPRs per lane); wide rows load it after them to stay inside the budget
+    constexpr bool PRE = NC <= 3;
+    f32x4 xv[R][NC], dr[PRE ? R : 1][PRE ? NC : 1];
     bf16x4 gy[R][NC];
     float mean[R], rstd[R];
 #pragma unroll
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict
         if (col < D) {
           xv[r][c] = *(const f32x4*)(x + (size_t)row * D + col);
           gy[r][c] = *(const bf16x4*)(dy + (size_t)row * D + col);
+          if constexpr (PRE) {
+            if (dres) dr[r][c] = *(const f32x4*)(dres + (size_t)row * D + col);
+          }
         }
       }
     }
@@ -142,7 +148,10 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_kernel(const bf16* __restrict
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rstd[r] * (g[c][e] - s1 - xh[c][e] * s2);
-          if (dres) o += *(const f32x4*)(dres + (size_t)row * D + col);
+          if (dres) {
+            if constexpr (PRE) o += dr[r][c];
+            else o += *(const f32x4*)(dres + (size_t)row * D + col);
+          }
           *(f32x4*)(dx + (size_t)row * D + col) = o;
           if (dxb) {
             const bf16x4 ob = __builtin_convertvector(o, bf16x4);
