@@ -38,9 +38,7 @@ def main():
         bias = torch.randn(N, device=dev, generator=g)
         ref = None
         for cfg, name in CFGS.items():
-            for swz in (3, 1):
-                if swz == 1 and epi == ops.EPI_F32_SLAB:
-                    continue
+            for swz in (3, 1):  # 3 = XCD tile order + LDS-staged stores; 1 = direct stores
                 lib.vtp_set_gemm_tuning(cfg, swz)
                 kw = {}
                 splits = 1
