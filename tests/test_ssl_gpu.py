@@ -86,6 +86,16 @@ def test_ssl_kernels_vs_torch():
     o.softmax_center(tl, center, 1 / 0.07, probs, Tt, Kp)
     pref = F.softmax((tl.float() - center) / 0.07, dim=-1)
     assert float((probs.float() - pref).abs().max()) < 2 ** -8 * float(pref.max()) + 1e-6
+    for Kbig in (65536, 8200 * 2):  # register-resident kernel (K <= 65536), full and ragged last chunk
+        tb = bf(torch.randn(3, Kbig, device=DEV, generator=g) * 2)
+        cb = torch.randn(Kbig, device=DEV, generator=g) * 0.1
+        pb = torch.empty(3, Kbig, dtype=torch.bfloat16, device=DEV)
+        o.softmax_center(tb, cb, 1 / 0.07, pb, 3, Kbig)
+        rb = F.softmax((tb.float() - cb) / 0.07, dim=-1)
+        assert float((pb.float() - rb).abs().max()) < 2 ** -8 * float(rb.max()) + 1e-6
+        o.softmax_center(tb, None, 1 / 0.07, pb, 3, Kbig)
+        rb = F.softmax(tb.float() / 0.07, dim=-1)
+        assert float((pb.float() - rb).abs().max()) < 2 ** -8 * float(rb.max()) + 1e-6
     sl = bf(torch.randn(Ts, Kp, device=DEV, generator=g) * 2)
     t0 = torch.tensor([0, 1, 2, 3, 4, 5, 0, -1, 2], dtype=torch.int32, device=DEV)
     t1 = torch.tensor([3, 4, -1, -1, -1, 0, -1, -1, -1], dtype=torch.int32, device=DEV)

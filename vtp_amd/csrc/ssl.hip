@@ -140,6 +140,70 @@ __global__ __launch_bounds__(256) void softmax_center_kernel(const bf16* __restr
   }
 }
 
+// register-resident variant for K <= 65536: 1024 threads hold the whole centred, scaled row (<= 64 values per lane), so logits
+// and the f32 centre are each read ONCE per row (the three-pass kernel above re-reads 128 KB + 256 KB per pass at K = 65536)
+__global__ __launch_bounds__(1024) void softmax_center_reg_kernel(const bf16* __restrict__ logits, const float* __restrict__ center,
+                                                                  float inv_temp, bf16* __restrict__ probs, int K) {
+  __shared__ float red[32];
+  const bf16* row = logits + (long)blockIdx.x * K;
+  float z[8][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int k = (c * 1024 + threadIdx.x) * 8;
+    if (k < K) {
+      const bf16x8 v = *(const bf16x8*)(row + k);
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      if (center) {
+        c0 = *(const f32x4*)(center + k);
+        c1 = *(const f32x4*)(center + k + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        z[c][e] = (bf2f(v[e]) - (e < 4 ? c0[e] : c1[e - 4])) * inv_temp;
+        mx = fmaxf(mx, z[c][e]);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int k = (c * 1024 + threadIdx.x) * 8;
+    if (k < K) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        z[c][e] = __expf(z[c][e] - mx);
+        se += z[c][e];
+      }
+    }
+  }
+  se = wave_sum(se);
+  if (lane == 0) red[16 + w] = se;
+  __syncthreads();
+  se = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) se += red[16 + i];
+  const float inv = 1.f / se;
+  bf16* out = probs + (long)blockIdx.x * K;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int k = (c * 1024 + threadIdx.x) * 8;
+    if (k < K) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(z[c][e] * inv);
+      *(bf16x8*)(out + k) = o;
+    }
+  }
+}
+
 // student cross-entropy against the sum of up to two teacher target rows:
 //   loss_sum += w * sum_targets( - sum_k p_t[k] * log_softmax(s * inv_temp)[k] )
 //   d_logits  = w * inv_temp * (n_targets * softmax(s * inv_temp) - sum_targets p_t)
@@ -236,8 +300,12 @@ extern "C" int vtp_weight_norm_bwd(const float* dW, const float* v, const float*
 extern "C" int vtp_softmax_center(const void* logits, const float* center, float inv_temp, void* probs, int T, int K,
                                   void* stream) {
   VTP_REQUIRE(logits && probs && T > 0 && K > 0 && K % 8 == 0, "vtp_softmax_center: bad argument (K %% 8 == 0)");
-  hipLaunchKernelGGL(softmax_center_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, center, inv_temp,
-                     (bf16*)probs, K);
+  if (K <= 65536 && K >= 8192)
+    hipLaunchKernelGGL(softmax_center_reg_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, center,
+                       inv_temp, (bf16*)probs, K);
+  else
+    hipLaunchKernelGGL(softmax_center_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, center, inv_temp,
+                       (bf16*)probs, K);
   return check_launch("softmax_center");
 }
 
