@@ -122,8 +122,9 @@ int vtp_cast_transpose_f32_bf16(const float* in, void* out, int R, int C, void* 
  * tile_start = exclusive prefix sum of per-record tile counts (64x64 tiles; mode 2: 256 elements per tile). */
 int vtp_prep_weights(const void* descs, int n, int total_tiles, void* stream);
 
-/* SwiGLU backward (ffn.py:80): given dh bf16 [M,H] and saved x12 bf16 [M,2H] (interleaved 8|8), writes dx12 bf16 [M,2H]. */
-int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, int M, int H, void* stream);
+/* SwiGLU backward (ffn.py:80): given dh bf16 [M,H] and saved x12 bf16 [M,2H] (interleaved 8|8), writes dx12 bf16 [M,2H].
+ * db12 (optional, f32 [2H] = [b1 | b2], accumulated): column sums of dx12 = the bias gradients of w1 / w2. */
+int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float* db12, int M, int H, void* stream);
 /* GELU backward (text MLP, block.py:399): dx = dy * gelu'(pre). */
 int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream);
 

@@ -25,7 +25,7 @@ SIGNATURES = {
     "vtp_cast_f32_bf16": [_P, _P, _L, _P],
     "vtp_cast_transpose_f32_bf16": [_P, _P, _I, _I, _P],
     "vtp_prep_weights": [_P, _I, _I, _P],
-    "vtp_swiglu_bwd": [_P, _P, _P, _I, _I, _P],
+    "vtp_swiglu_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "vtp_gelu_bwd": [_P, _P, _P, _L, _P],
     "vtp_pixel_shuffle16": [_P, _P, _I, _I, _I, _P],
     "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],

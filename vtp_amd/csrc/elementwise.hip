@@ -295,27 +295,63 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepDesc* __res
 }
 
 // ---------------------------------------------------------------- SwiGLU / GELU backward
+// dx12 = d(hidden)/d(x12) * dh in the interleaved [M, 2H] layout.  A wave covers 64 consecutive 8-column groups of one row
+// (2 KiB contiguous of x12); the 4 waves of a workgroup take different rows (2 in flight each) and walk the row dimension, so
+// the bias gradients of w1 / w2 -- column sums of the bf16 dx12 -- accumulate in registers, are reduced across the 4 waves
+// through LDS and leave as one atomic per column per workgroup (db12 f32 [2H] = [b1 | b2], may be null).
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ x12,
-                                                         bf16* __restrict__ dx12, int M, int H) {
-  const int g8 = H / 8;
-  const long total = (long)M * g8;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-    const int g = (int)(idx % g8);
-    const long m = idx / g8;
-    bf16x8 d = *(const bf16x8*)(dh + m * H + 8 * g);
-    bf16x8 x1 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g);
-    bf16x8 x2 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g + 8);
-    bf16x8 o1, o2;
+                                                         bf16* __restrict__ dx12, float* __restrict__ db12, int M, int H) {
+  __shared__ float red[4][64 * 16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = blockIdx.y * 64 + lane;
+  const bool live = g < H / 8;
+  float s1[8], s2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = bf2f(x1[e]), b = bf2f(x2[e]), gd = bf2f(d[e]);
-      const float sg = sigmoid_f(a);
-      const float gs = bf2f(f2bf(gd * b));                  // grad wrt silu(x1) (bf16 like eager autograd)
-      o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));    // silu'
-      o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));               // grad wrt x2 = dh * silu(x1)
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const int step = gridDim.x * 4;
+  if (live) {
+    for (int m0 = blockIdx.x * 4 + wv; m0 < M; m0 += 2 * step) {
+      bf16x8 d[2], x1[2], x2[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const long m = min(m0 + r * step, M - 1);
+        d[r] = *(const bf16x8*)(dh + m * H + 8 * g);
+        x1[r] = *(const bf16x8*)(x12 + m * 2L * H + 16 * g);
+        x2[r] = *(const bf16x8*)(x12 + m * 2L * H + 16 * g + 8);
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const long m = m0 + r * step;
+        if (m >= M) break;
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = bf2f(x1[r][e]), b = bf2f(x2[r][e]), gd = bf2f(d[r][e]);
+          const float sg = sigmoid_f(a);
+          const float gs = bf2f(f2bf(gd * b));                  // grad wrt silu(x1) (bf16 like eager autograd)
+          o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));    // silu'
+          o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));               // grad wrt x2 = dh * silu(x1)
+          s1[e] += bf2f(o1[e]);
+          s2[e] += bf2f(o2[e]);
+        }
+        *(bf16x8*)(dx12 + m * 2L * H + 16 * g) = o1;
+        *(bf16x8*)(dx12 + m * 2L * H + 16 * g + 8) = o2;
+      }
     }
-    *(bf16x8*)(dx12 + m * 2L * H + 16 * g) = o1;
-    *(bf16x8*)(dx12 + m * 2L * H + 16 * g + 8) = o2;
+  }
+  if (db12 == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[wv][lane * 16 + e] = s1[e];
+    red[wv][lane * 16 + 8 + e] = s2[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+    const int l = i >> 4, e = i & 15, gg = blockIdx.y * 64 + l;
+    if (gg < H / 8) {
+      const float t = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+      unsafeAtomicAdd(db12 + (e < 8 ? 8 * gg + e : H + 8 * gg + e - 8), t);
+    }
   }
 }
 
@@ -510,10 +546,14 @@ extern "C" int vtp_prep_weights(const void* descs, int n, int total_tiles, void*
   return check_launch("prep_weights");
 }
 
-extern "C" int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, int M, int H, void* stream) {
+extern "C" int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float* db12, int M, int H, void* stream) {
   VTP_REQUIRE(dh && x12 && dx12 && M > 0 && H > 0 && H % 8 == 0, "vtp_swiglu_bwd: bad argument (H %% 8 == 0)");
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * (H / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)dh, (const bf16*)x12, (bf16*)dx12, M, H);
+  const int gy = cdiv(H / 8, 64);
+  int gx = 2048 / gy;  // ~8 workgroups per CU in total
+  if (gx > (M + 7) / 8) gx = (M + 7) / 8;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh, (const bf16*)x12,
+                     (bf16*)dx12, db12, M, H);
   return check_launch("swiglu_bwd");
 }
 

@@ -463,9 +463,12 @@ class Stack:
             # ---- FFN: x_out = x_mid + w3(act(...))
             linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh, bias_grad_done=dy_colsum_done or i < self.depth - 1)
             if vit:
-                ops.swiglu_bwd(dh, pre, dpre, M, H)
+                # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
+                # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
+                fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1"
+                ops.swiglu_bwd(dh, pre, dpre, M, H, db12=b.w12.gb1 if fuse else None)
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
-                           swiglu_h=H)
+                           swiglu_h=H, bias_grad_done=fuse)
             else:
                 ops.gelu_bwd(dh, pre, dpre, M * H)
                 linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn)

@@ -98,8 +98,8 @@ def prep_weights(descs, n, total_tiles):
     _lib.check(_lib_().vtp_prep_weights(_p(descs), n, total_tiles, _s()), "vtp_prep_weights")
 
 
-def swiglu_bwd(dh, x12, dx12, M, H):
-    _lib.check(_lib_().vtp_swiglu_bwd(_p(dh), _p(x12), _p(dx12), M, H, _s()), "vtp_swiglu_bwd")
+def swiglu_bwd(dh, x12, dx12, M, H, db12=None):
+    _lib.check(_lib_().vtp_swiglu_bwd(_p(dh), _p(x12), _p(dx12), _p(db12), M, H, _s()), "vtp_swiglu_bwd")
 
 
 def gelu_bwd(dy, pre, dx, n):
