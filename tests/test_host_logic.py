@@ -108,3 +108,62 @@ def test_bucketed_allreduce_world2_gloo():
         exp[4:16] = base[4:16] * 3   # sum over ranks of (rank+1)
         exp[24:40] = base[24:40] * 3
         assert torch.equal(out[r], exp)
+
+
+def test_ssl_index_plan_matches_reference_buffer_layout():
+    """build_ssl_indices (host): teacher cls rows are view-swapped (vtp.py:425-426), masked patch rows address the
+    [B, 1+hw, D] stream, per-image iBOT weights are 1 / n_masked(image), padding rows are inert."""
+    import numpy as np
+    from vtp_amd.ssl_engine import build_ssl_indices
+    B, hw, n_local, hw_l = 3, 16, 2, 4
+    rng = np.random.default_rng(0)
+    masks = np.zeros((2 * B, hw), bool)
+    masks[0, [1, 5]] = True
+    masks[4, [0, 2, 3]] = True
+    p = build_ssl_indices(masks, B, hw, n_local, hw_l, dino_weight=1.0, ibot_weight=2.0, pad_to=8)
+    N = hw + 1
+    assert p["n_masked"] == 5 and p["Tm"] == 8 and p["Ts"] == n_local * B + 2 * B + 8
+    assert p["teacher_src"][:2 * B].tolist() == [b * N for b in (3, 4, 5, 0, 1, 2)]
+    assert p["teacher_src"][2 * B:2 * B + 5].tolist() == [0 * N + 2, 0 * N + 6, 4 * N + 1, 4 * N + 3, 4 * N + 4]
+    assert (p["teacher_src"][2 * B + 5:] == -1).all()
+    assert p["student_local_src"].tolist() == [i * (hw_l + 1) for i in range(n_local * B)]
+    assert p["student_global_src"][:2 * B].tolist() == [b * N for b in range(2 * B)]
+    terms = 2 * 1 + n_local * 2
+    w = p["w"]
+    assert np.allclose(w[:n_local * B + 2 * B], 1.0 / (B * terms))
+    m0 = n_local * B + 2 * B
+    assert np.allclose(w[m0:m0 + 5], [2.0 / 2 / B] * 2 + [2.0 / 3 / B] * 3) and (w[m0 + 5:] == 0).all()
+    # local crops are compared with both teacher views, global crops with the other view only
+    assert p["t0"][:n_local * B].tolist() == [0, 1, 2, 0, 1, 2] and p["t1"][:n_local * B].tolist() == [3, 4, 5, 3, 4, 5]
+    assert (p["t1"][n_local * B:] == -1).all()
+
+
+def test_wgrad_split_rule_and_overlap_lanes():
+    from vtp_amd.engine import OVERLAP, _wgrad_splits
+    # tiles x splits stays within one resident wave of 512 workgroups, slices keep >= 8 k-tiles, at most 16 slices
+    for rows, cols, k in ((2304, 768, 34144), (768, 768, 34144), (4096, 768, 8224), (768, 2048, 34144), (65536, 256, 3000), (64, 64, 100)):
+        s = _wgrad_splits(rows, cols, k)
+        tiles = -(-rows // 128) * -(-cols // 128)
+        assert 1 <= s <= 16 and (s == 1 or (tiles * s <= 512 and k // s >= 512)), (rows, cols, k, s)
+    assert _wgrad_splits(768, 768, 34144) == 14 and _wgrad_splits(768, 2048, 34144) == 5
+    assert OVERLAP._lane == 0
+    with OVERLAP.lane(1):
+        assert OVERLAP._lane == 1
+        with OVERLAP.lane(0):
+            assert OVERLAP._lane == 0
+        assert OVERLAP._lane == 1
+    assert OVERLAP._lane == 0
+
+
+def test_lpips_module_has_the_reference_state_dict_layout_and_no_cpu_fallback():
+    from oracle import lpips_oracle as L
+    from vtp_amd import LPIPS
+    m = LPIPS(use_dropout=True)
+    sd = L.make_state(1)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    assert all(tuple(m.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+    m.load_state_dict(sd, strict=True)
+    assert abs(LPIPS.forward_gflop(224, 224) - 30.7) < 0.2  # 15.35 GMAC for VGG16 features at 224^2 (SURVEY 8a a18)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
+    assert set(LPIPS(use_dropout=False).state_dict().keys()) == {k.replace(".model.1.", ".model.0.") for k in sd}
