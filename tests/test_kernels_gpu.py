@@ -357,6 +357,9 @@ def test_swiglu_gelu_bwd_adamw_ema_assemble():
     dest = (g_ // 16) * 8 + g_ % 8 + torch.where((g_ % 16) >= 8, H, 0)   # interleaved column -> [b1 | b2] slot
     cs = torch.zeros(2 * H, device=DEV).index_add_(0, dest, dx12.float().sum(0)) + 2.0
     assert float((db12 - cs).abs().max()) <= 1e-4 * float(dx12.float().abs().sum(0).max()) + 1e-4, "swiglu_bwd bias grads"
+    dx12_plain = torch.empty_like(x12)
+    o.swiglu_bwd(dh, x12, dx12_plain, M, H)  # default kernel (no fused bias gradients): identical output
+    assert torch.equal(dx12_plain, dx12)
     a, b = x1.float().requires_grad_(True), x2.float().requires_grad_(True)
     (F.silu(a) * b).backward(dh.float())
     ref = interleave(bf(a.grad).T.contiguous(), bf(b.grad).T.contiguous()).T

@@ -295,12 +295,37 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepDesc* __res
 }
 
 // ---------------------------------------------------------------- SwiGLU / GELU backward
-// dx12 = d(hidden)/d(x12) * dh in the interleaved [M, 2H] layout.  A wave covers 64 consecutive 8-column groups of one row
+// dx12 = d(hidden)/d(x12) * dh in the interleaved [M, 2H] layout: plain grid-stride elementwise kernel (the default path)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ x12,
+                                                         bf16* __restrict__ dx12, int M, int H) {
+  const int g8 = H / 8;
+  const long total = (long)M * g8;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    const int g = (int)(idx % g8);
+    const long m = idx / g8;
+    bf16x8 d = *(const bf16x8*)(dh + m * H + 8 * g);
+    bf16x8 x1 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g);
+    bf16x8 x2 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g + 8);
+    bf16x8 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = bf2f(x1[e]), b = bf2f(x2[e]), gd = bf2f(d[e]);
+      const float sg = sigmoid_f(a);
+      const float gs = bf2f(f2bf(gd * b));                  // grad wrt silu(x1) (bf16 like eager autograd)
+      o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));    // silu'
+      o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));               // grad wrt x2 = dh * silu(x1)
+    }
+    *(bf16x8*)(dx12 + m * 2L * H + 16 * g) = o1;
+    *(bf16x8*)(dx12 + m * 2L * H + 16 * g + 8) = o2;
+  }
+}
+
+// same, with the w1 / w2 bias gradients fused (used when db12 != null).  A wave covers 64 consecutive 8-column groups of one row
 // (2 KiB contiguous of x12); the 4 waves of a workgroup take different rows (2 in flight each) and walk the row dimension, so
 // the bias gradients of w1 / w2 -- column sums of the bf16 dx12 -- accumulate in registers, are reduced across the 4 waves
 // through LDS and leave as one atomic per column per workgroup (db12 f32 [2H] = [b1 | b2], may be null).
-__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ x12,
-                                                         bf16* __restrict__ dx12, float* __restrict__ db12, int M, int H) {
+__global__ __launch_bounds__(256) void swiglu_bwd_rows_kernel(const bf16* __restrict__ dh, const bf16* __restrict__ x12,
+                                                              bf16* __restrict__ dx12, float* __restrict__ db12, int M, int H) {
   __shared__ float red[4][64 * 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.y * 64 + lane;
@@ -339,7 +364,6 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict_
       }
     }
   }
-  if (db12 == nullptr) return;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     red[wv][lane * 16 + e] = s1[e];
@@ -552,8 +576,12 @@ extern "C" int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float
   int gx = 2048 / gy;  // ~8 workgroups per CU in total
   if (gx > (M + 7) / 8) gx = (M + 7) / 8;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh, (const bf16*)x12,
-                     (bf16*)dx12, db12, M, H);
+  if (db12)
+    hipLaunchKernelGGL(swiglu_bwd_rows_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16*)dh,
+                       (const bf16*)x12, (bf16*)dx12, db12, M, H);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * (H / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)dh, (const bf16*)x12, (bf16*)dx12, M, H);
   return check_launch("swiglu_bwd");
 }
 
