@@ -79,12 +79,16 @@ int vtp_rope_qk(void* qkv, const void* sin, const void* cos, int B, int N, int h
 
 /* ---- attention (attention.py:124 F.scaled_dot_product_attention; text: nn.MultiheadAttention causal) ----
  * q/k/v/o are bf16 with element strides: batch stride `sb`, token stride `sn`, head h at +h*64 (head_dim is 64).
- * lse f32 [B, heads, N] (natural-log-sum-exp of scale*q.k).  causal != 0 masks key > query. */
+ * lse f32 [B, heads, N] (natural-log-sum-exp of scale*q.k).  causal != 0 masks key > query.
+ * bwd: delta f32 [B, heads, N] is scratch (rowsum(dO*O)).  rope_sin / rope_cos (bf16 [N - rope_prefix, 64], both or neither):
+ * dq and dk are returned as gradients w.r.t. the UN-rotated q, k (the inverse of vtp_rope_qk applied with the same eager-bf16
+ * rounding) -- fused into the kernels' stores for short sequences, a follow-up pass otherwise (needs the packed qkv layout). */
 int vtp_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int N, int heads,
                  long sb_qkv, long sn_qkv, long sb_o, long sn_o, float scale, int causal, void* stream);
 int vtp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                 float* delta /* scratch f32 [B,heads,N] */, void* dq, void* dk, void* dv, int B, int N, int heads,
-                 long sb_qkv, long sn_qkv, long sb_o, long sn_o, float scale, int causal, void* stream);
+                 float* delta, void* dq, void* dk, void* dv, const void* rope_sin, const void* rope_cos, int rope_prefix,
+                 int B, int N, int heads, long sb_qkv, long sn_qkv, long sb_o, long sn_o, float scale, int causal,
+                 void* stream);
 
 /* ---- data movement / elementwise --------------------------------------------------------------- */
 /* im2col for the 16x16/s16 patch-embed conv (embeddings.py:58,64-69): img f32 [B,3,H,W] -> patches bf16 [B*h*w, 768],

@@ -250,6 +250,17 @@ def test_attention_fwd_bwd(B, N, heads, causal):
     for nm, a, r in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         e = float((a.float() - r).norm() / r.norm())
         assert e < 1.5e-2, f"attn_bwd {nm}: relF {e:.3e}"
+    if not causal:
+        # inverse RoPE fused into the backward (short sequences: in the kernels' stores; long: appended pass) is bit-identical
+        # to running vtp_rope_qk(inverse) on the plain result; the cls row (prefix 1) stays un-rotated
+        sin = bf(torch.randn(N - 1, 64, device=DEV, generator=g))
+        cos = bf(torch.randn(N - 1, 64, device=DEV, generator=g))
+        want = dqkv.clone()
+        o.rope_qk(want, sin, cos, B, N, heads, 1, inverse=True)
+        got = torch.full_like(dqkv, float("nan"))
+        o.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, d_o, lse, delta, got, got[:, D:], got[:, 2 * D:], B, N, heads,
+                   N * 3 * D, 3 * D, N * D, D, scale, causal, rope=(sin, cos), rope_prefix=1)
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
 
 
 # ----------------------------------------------------------------------------------------------------------- data movement

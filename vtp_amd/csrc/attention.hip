@@ -388,9 +388,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 // short non-causal sequences: K/V (Q/dO) resident in LDS, one workgroup per (image, head) -- attention_resident.hip
 int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int N, int heads, long sb,
                       long sn, long sbo, long sno, float scale, hipStream_t s);
-int attn_resident_bwd(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
-                      void* dq, void* dk, void* dv, int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale,
-                      hipStream_t s);
+int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                      float* delta, void* dq, void* dk, void* dv, const void* rope_sin, const void* rope_cos, int rope_prefix,
+                      int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale, hipStream_t s);
 static bool use_resident(int N, int causal) {
   static const bool on = !(getenv("VTP_ATTN_RESIDENT") && atoi(getenv("VTP_ATTN_RESIDENT")) == 0);
   return on && !causal && N <= 320;
@@ -421,22 +421,29 @@ extern "C" int vtp_attn_fwd(const void* q, const void* k, const void* v, void* o
   return check_launch("attn_fwd");
 }
 
+extern "C" int vtp_rope_qk(void* qkv, const void* sin, const void* cos, int B, int N, int heads, int prefix, int inverse,
+                           void* stream);
+
 extern "C" int vtp_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                            float* delta, void* dq, void* dk, void* dv, int B, int N, int heads, long sb_qkv, long sn_qkv,
-                            long sb_o, long sn_o, float scale, int causal, void* stream) {
+                            float* delta, void* dq, void* dk, void* dv, const void* rope_sin, const void* rope_cos,
+                            int rope_prefix, int B, int N, int heads, long sb_qkv, long sn_qkv, long sb_o, long sn_o,
+                            float scale, int causal, void* stream) {
   VTP_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "vtp_attn_bwd: null pointer");
+  VTP_REQUIRE((rope_sin == nullptr) == (rope_cos == nullptr), "vtp_attn_bwd: rope_sin and rope_cos go together");
+  VTP_REQUIRE(!rope_sin || (rope_prefix >= 0 && rope_prefix <= N), "vtp_attn_bwd: rope_prefix must be in [0, N]");
   if (int e = check_attn("vtp_attn_bwd", B, N, heads, sb_qkv, sn_qkv, sb_o, sn_o)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (use_resident(N, causal))  // delta and the inverse RoPE of dq / dk are fused into the resident kernels
+    return attn_resident_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, rope_sin, rope_cos, rope_prefix, B, N, heads, sb_qkv,
+                             sn_qkv, sb_o, sn_o, scale, s);
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)o; a.d_o = (const bf16*)d_o;
   a.lse = (float*)lse; a.delta = delta; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
   a.B = B; a.N = N; a.heads = heads; a.sb = sb_qkv; a.sn = sn_qkv; a.sbo = sb_o; a.sno = sn_o; a.scale = scale;
-  hipStream_t s = (hipStream_t)stream;
   const long rows8 = (long)B * heads * N * 8;
   int dblocks = (int)((rows8 + 255) / 256);
   if (dblocks > 4096) dblocks = 4096;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(dblocks), dim3(256), 0, s, a);
-  if (use_resident(N, causal))
-    return attn_resident_bwd(q, k, v, d_o, lse, delta, dq, dk, dv, B, N, heads, sb_qkv, sn_qkv, sb_o, sn_o, scale, s);
   dim3 grid(cdiv(N, 128), heads, B);
   if (causal) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, s, a);
@@ -445,5 +452,11 @@ extern "C" int vtp_attn_bwd(const void* q, const void* k, const void* v, const v
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, s, a);
   }
-  return check_launch("attn_bwd");
+  if (int e = check_launch("attn_bwd")) return e;
+  if (rope_sin) {  // tiled path: the standalone inverse-RoPE kernel on the packed [*, 3*heads*64] gradient buffer
+    VTP_REQUIRE((const bf16*)dk == (const bf16*)dq + heads * 64 && sn_qkv == 3L * heads * 64 && sb_qkv == (long)N * sn_qkv,
+                "vtp_attn_bwd: fused inverse RoPE on the tiled path needs the packed qkv gradient layout");
+    return vtp_rope_qk(dq, rope_sin, rope_cos, B, N, heads, rope_prefix, 1, stream);
+  }
+  return VTP_OK;
 }

@@ -23,7 +23,9 @@ struct AttnResArgs {
   const bf16 *q, *k, *v, *o, *d_o;
   bf16 *out, *dq, *dk, *dv;
   float* lse;
-  const float* delta;
+  float* delta;           // written by the dQ kernel (rowsum(dO * O)), read by the dK/dV kernel that follows it
+  const bf16 *rope_sin, *rope_cos;  // [hw, 64] tables or null: dq / dk leave inverse-rotated (gradient w.r.t. the un-rotated q, k)
+  int rope_prefix;
   int B, N, heads, npad;  // npad = N rounded up to 32
   long sb, sn, sbo, sno;
   float scale;
@@ -72,6 +74,27 @@ __device__ __forceinline__ void zero16r(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 __device__ __forceinline__ void wait_all_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// inverse RoPE of one gradient row held as two f32x4 pieces (d = d0..d0+3 and d0+32..d0+35), bit-identical to
+// rope_qk_kernel<true> applied to the bf16-rounded values: dx1 = g1*cos1 + g2*sin2 ; dx2 = g2*cos2 - g1*sin1
+__device__ __forceinline__ void store_grad_pair(bf16* row, int d0, f32x4 lo, f32x4 hi, const bf16* sin_t, const bf16* cos_t, long t) {
+  bf16x4 a4 = __builtin_convertvector(lo, bf16x4), b4 = __builtin_convertvector(hi, bf16x4);
+  if (sin_t) {
+    const bf16x4 c1 = *(const bf16x4*)(cos_t + t + d0), c2 = *(const bf16x4*)(cos_t + t + d0 + 32);
+    const bf16x4 s1 = *(const bf16x4*)(sin_t + t + d0), s2 = *(const bf16x4*)(sin_t + t + d0 + 32);
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bf2f(a4[e]), b = bf2f(b4[e]);
+      o1[e] = f2bf(bf2f(f2bf(a * bf2f(c1[e]))) + bf2f(f2bf(b * bf2f(s2[e]))));
+      o2[e] = f2bf(bf2f(f2bf(b * bf2f(c2[e]))) + bf2f(f2bf(-a * bf2f(s1[e]))));
+    }
+    a4 = o1;
+    b4 = o2;
+  }
+  *(bf16x4*)(row + d0) = a4;
+  *(bf16x4*)(row + d0 + 32) = b4;
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) {
@@ -180,7 +203,18 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   }
   const long srow = ((long)b * p.heads + h) * p.N + qc;
   const float lse2 = p.lse[srow] * LOG2E_R;
-  const float dlt = p.delta[srow];
+  float dlt = 0.f;  // delta = rowsum(dO * O): this lane's 32 elements + the other half-wave's
+  {
+    const bf16* orow = p.o + (long)b * p.sbo + h * 64 + (long)qc * p.sno + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 ov = *(const bf16x8*)(orow + ks * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dlt += bf2f(ov[e]) * bf2f(dof[ks][e]);
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (hi == 0 && qi < p.N) p.delta[srow] = dlt;
+  }
   wait_all_dma();
   __syncthreads();
   const float sc2 = p.scale * LOG2E_R;
@@ -213,15 +247,18 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   }
   if (qi >= p.N) return;
   bf16* drow = p.dq + (long)b * p.sb + (long)qi * p.sn + h * 64;
+  const bool rot = p.rope_sin && qi >= p.rope_prefix;
+  const long t = (long)(qi - p.rope_prefix) * 64;
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int g = 0; g < 4; ++g) {
+    f32x4 lo, hv;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = dq[db][4 * g + e];
-      *(bf16x4*)(drow + db * 32 + 8 * g + 4 * hi) = __builtin_convertvector(v, bf16x4);
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = dq[0][4 * g + e];
+      hv[e] = dq[1][4 * g + e];
     }
+    store_grad_pair(drow, 8 * g + 4 * hi, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos, t);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -296,19 +333,21 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   if (ki >= p.N) return;
   bf16* krow = p.dk + (long)b * p.sb + (long)ki * p.sn + h * 64;
   bf16* vrow = p.dv + (long)b * p.sb + (long)ki * p.sn + h * 64;
+  const bool rot = p.rope_sin && ki >= p.rope_prefix;
+  const long t = (long)(ki - p.rope_prefix) * 64;
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int g = 0; g < 4; ++g) {
+    f32x4 lo, hv, c0, c1;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a, c;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = dk[db][4 * g + e];
-        c[e] = dv[db][4 * g + e];
-      }
-      *(bf16x4*)(krow + db * 32 + 8 * g + 4 * hi) = __builtin_convertvector(a, bf16x4);
-      *(bf16x4*)(vrow + db * 32 + 8 * g + 4 * hi) = __builtin_convertvector(c, bf16x4);
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = dk[0][4 * g + e];
+      hv[e] = dk[1][4 * g + e];
+      c0[e] = dv[0][4 * g + e];
+      c1[e] = dv[1][4 * g + e];
     }
+    store_grad_pair(krow, 8 * g + 4 * hi, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos, t);
+    store_grad_pair(vrow, 8 * g + 4 * hi, c0, c1, nullptr, nullptr, 0);
+  }
 }
 
 template <typename K>
@@ -331,12 +370,13 @@ int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, floa
   return check_launch("attn_fwd_resident");
 }
 
-int attn_resident_bwd(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
-                      void* dq, void* dk, void* dv, int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale,
-                      hipStream_t s) {
+int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                      float* delta, void* dq, void* dk, void* dv, const void* rope_sin, const void* rope_cos, int rope_prefix,
+                      int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale, hipStream_t s) {
   AttnResArgs a = {};
-  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.d_o = (const bf16*)d_o; a.lse = (float*)lse;
-  a.delta = delta; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)o; a.d_o = (const bf16*)d_o;
+  a.lse = (float*)lse; a.delta = delta; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
+  a.rope_sin = (const bf16*)rope_sin; a.rope_cos = (const bf16*)rope_cos; a.rope_prefix = rope_prefix;
   a.B = B; a.N = N; a.heads = heads; a.npad = (N + 31) / 32 * 32; a.sb = sb; a.sn = sn; a.sbo = sbo; a.sno = sno; a.scale = scale;
   static bool attr = false;
   if (!attr) {

@@ -480,10 +480,10 @@ class Stack:
             for r0, Bs, Ns, rp in self._rows(segs):
                 r1 = r0 + Bs * Ns
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
+                # dq / dk come back as gradients w.r.t. the un-rotated q, k (inverse RoPE fused into the attention backward)
                 ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
-                             dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal)
-                if rp is not None:
-                    ops.rope_qk(dq_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens, inverse=True)
+                             dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
+                             rope=rp, rope_prefix=prefix_tokens)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
             ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind,
                          dx_colsum=self.blocks[i - 1].w3.gb if i > 0 else None)

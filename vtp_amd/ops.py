@@ -60,9 +60,12 @@ def attn_fwd(q, k, v, o, lse, B, N, heads, sb, sn, sbo, sno, scale, causal=False
                                     _s()), "vtp_attn_fwd")
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, N, heads, sb, sn, sbo, sno, scale, causal=False):
-    _lib.check(_lib_().vtp_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, N,
-                                    heads, sb, sn, sbo, sno, scale, int(causal), _s()), "vtp_attn_bwd")
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, N, heads, sb, sn, sbo, sno, scale, causal=False, rope=None,
+             rope_prefix=0):
+    """rope = (sin, cos): dq / dk come back as gradients w.r.t. the un-rotated q, k (inverse RoPE fused / appended)."""
+    rs, rc = (rope[0], rope[1]) if rope is not None else (None, None)
+    _lib.check(_lib_().vtp_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(rs),
+                                    _p(rc), rope_prefix, B, N, heads, sb, sn, sbo, sno, scale, int(causal), _s()), "vtp_attn_bwd")
 
 
 def im2col16(img, patches, B, H, W):
