@@ -11,6 +11,7 @@
 //
 // Forward is two-pass over the resident keys (row maximum first, then exp / sum / PV): no running rescale of the accumulator.
 #include "common.h"
+#include <cstdlib>
 #include "vtp_hip.h"
 
 namespace vtp {
@@ -74,6 +75,23 @@ __device__ __forceinline__ void zero16r(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 __device__ __forceinline__ void wait_all_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most n (wave-uniform, small) vector-memory operations of this wave are outstanding
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
+  }
+}
 
 // inverse RoPE of one gradient row held as two f32x4 pieces (d = d0..d0+3 and d0+32..d0+35), bit-identical to
 // rope_qk_kernel<true> applied to the bf16-rounded values: dx1 = g1*cos1 + g2*sin2 ; dx2 = g2*cos2 - g1*sin1
@@ -104,7 +122,8 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, hi = lane >> 5;
   const int h = blockIdx.x, b = blockIdx.y;
   const bf16* qb = p.q + (long)b * p.sb + h * 64;
-  const int q0 = wave * 32, qi = q0 + (lane & 31);
+  const int q0 = (blockIdx.z * nwaves + wave) * 32, qi = q0 + (lane & 31);  // a head's query blocks are split over gridDim.z
+  const bool active = q0 < p.npad;                                          // workgroups (each stages all of K / V)
   bf16x8 qf[4];
   {  // issued first: vmcnt retires in order, and pass 1 needs q and K but not V
     const bf16* qr = qb + (long)min(qi, p.N - 1) * p.sn + hi * 8;
@@ -113,16 +132,15 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
   }
   stage_resident(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Ks, wave, nwaves, lane);
   stage_resident(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Vs, wave, nwaves, lane);
-  // every wave issues exactly (npad/8) / (npad/32) = 4 pieces per matrix: the 4 youngest operations are the V pieces, which
-  // stream in behind pass 1
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // the youngest operations of this wave are its V pieces, which stream in behind pass 1 (vmcnt retires in order)
+  wait_vmcnt_upto(((p.npad >> 3) - wave + nwaves - 1) / nwaves);
   __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain vmcnt (the V pieces) first
   asm volatile("" ::: "memory");
   const float sc2 = p.scale * LOG2E_R;
   const int nkb = p.npad >> 5, last = nkb - 1;
   // pass 1: row maximum of the raw scores (scale > 0 commutes with max)
   float mx = -INFINITY;
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = 0; kb < (active ? nkb : 0); ++kb) {
     f32x16 s;
     zero16r(s);
 #pragma unroll
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
   const float m2 = mx * sc2;
   wait_all_dma();   // V landed
   __syncthreads();
+  if (!active) return;
   // pass 2: p = exp2(s*sc2 - m2), l = sum p, O^T += V^T P^T
   f32x16 oacc[2];
   zero16r(oacc[0]);
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   const int h = blockIdx.x, b = blockIdx.y;
   stage_resident(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Ks, wave, nwaves, lane);
   stage_resident(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Vs, wave, nwaves, lane);
-  const int q0 = wave * 32, qi = q0 + (lane & 31), qc = min(qi, p.N - 1);
+  const int q0 = (blockIdx.z * nwaves + wave) * 32, qi = q0 + (lane & 31), qc = min(qi, p.N - 1);
   bf16x8 qf[4], dof[4];
   {
     const bf16* qr = p.q + (long)b * p.sb + h * 64 + (long)qc * p.sn + hi * 8;
@@ -217,6 +236,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   }
   wait_all_dma();
   __syncthreads();
+  if (q0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
   const int nkb = p.npad >> 5, last = nkb - 1;
   f32x16 dq[2];
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
     lse_s[i] = p.lse[srow0 + qn] * LOG2E_R;
     dlt_s[i] = p.delta[srow0 + qn];
   }
-  const int k0 = wave * 32, ki = k0 + (lane & 31), kc = min(ki, p.N - 1);
+  const int k0 = (blockIdx.z * nwaves + wave) * 32, ki = k0 + (lane & 31), kc = min(ki, p.N - 1);
   bf16x8 kf[4], vf[4];
   {
     const bf16* kr = p.k + (long)b * p.sb + h * 64 + (long)kc * p.sn + hi * 8;
@@ -291,6 +311,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   }
   wait_all_dma();
   __syncthreads();
+  if (k0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
   const int nqb = p.npad >> 5, last = nqb - 1;
   f32x16 dk[2], dv[2];
@@ -350,6 +371,16 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   }
 }
 
+// a head with >= 4 row blocks is split over two workgroups (each stages the whole K / V or Q / dO image, 2 x 37 KB at N = 257):
+// two of them fit a CU, so one's staging overlaps the other's key loop
+// -- worth it only while heads x images leaves CUs short of work (<= 512 workgroups: +1.2 % on the 32-image rec step, -0.4 %
+// when the 64-image passes already run three full rounds and the second copy of K / V is pure extra traffic)
+static int res_waves_per_block(int nw, int groups) {
+  static const int mode = getenv("VTP_ATTN_SPLIT") ? atoi(getenv("VTP_ATTN_SPLIT")) : -1;  // 0 never, 1 always, -1 by size
+  const bool split = mode == 1 || (mode != 0 && groups <= 512);
+  return (split && nw >= 4) ? (nw + 1) / 2 : nw;
+}
+
 template <typename K>
 static void set_lds(K kern, int bytes) {
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -366,7 +397,8 @@ int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, floa
     set_lds(attn_fwd_res_kernel, 2 * RES_MAXN * 128);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(heads, B), dim3(64 * (a.npad / 32)), 2 * a.npad * 128, s, a);
+  const int nw = a.npad / 32, wpb = res_waves_per_block(nw, heads * B);
+  hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(heads, B, (nw + wpb - 1) / wpb), dim3(64 * wpb), 2 * a.npad * 128, s, a);
   return check_launch("attn_fwd_resident");
 }
 
@@ -384,7 +416,8 @@ int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o
     set_lds(attn_bwd_dkv_res_kernel, 2 * RES_MAXN * 128 + 8 * RES_MAXN);
     attr = true;
   }
-  const dim3 grid(heads, B), block(64 * (a.npad / 32));
+  const int nw = a.npad / 32, wpb = res_waves_per_block(nw, heads * B);
+  const dim3 grid(heads, B, (nw + wpb - 1) / wpb), block(64 * wpb);
   hipLaunchKernelGGL(attn_bwd_dq_res_kernel, grid, block, 2 * a.npad * 128, s, a);
   hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, grid, block, 2 * a.npad * 128 + 8 * a.npad, s, a);
   return check_launch("attn_bwd_resident");
