@@ -43,7 +43,7 @@ def rope_periods(head_dim: int = 64, base: float = 100.0, dtype=torch.bfloat16) 
 def rope_table(H: int, W: int, periods: Tensor) -> Tuple[Tensor, Tensor]:
     """(sin, cos), each [H*W, D_head], in periods.dtype -- 'separate' coordinate normalisation,
     no train-time augmentation.  embeddings.py:131-180 (exact op order, so bf16 rounding matches)."""
-    dd = {"dtype": periods.dtype}
+    dd = {"dtype": periods.dtype, "device": periods.device}  # device-aware: the GPU-autocast comparator of the tests
     coords_h = torch.arange(0.5, H, **dd) / H
     coords_w = torch.arange(0.5, W, **dd) / W
     coords = torch.stack(torch.meshgrid(coords_h, coords_w, indexing="ij"), dim=-1)
@@ -248,7 +248,7 @@ def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True) 
     for i in range(_depth(sd, "text_transformer.resblocks.")):
         x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads)
     x = layernorm(x, sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
-    x = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
+    x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
     x = x @ sd["text_projection"]
     return F.normalize(x, dim=-1) if normalize else x
 
@@ -278,7 +278,7 @@ def l1_loss(rec: Tensor, target: Tensor) -> Tensor:
 def clip_loss(img_f: Tensor, txt_f: Tensor, logit_scale_exp: Tensor) -> Tensor:
     """OpenCLIP ClipLoss (single process): 0.5*(CE(s*I*T^T) + CE(s*T*I^T)), labels=arange."""
     logits = logit_scale_exp * img_f @ txt_f.T
-    labels = torch.arange(logits.shape[0])
+    labels = torch.arange(logits.shape[0], device=logits.device)
     return 0.5 * (F.cross_entropy(logits, labels) + F.cross_entropy(logits.T, labels))
 
 
