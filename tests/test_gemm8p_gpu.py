@@ -1,0 +1,144 @@
+"""The 256x256 8-phase GEMM main loop (vtp_amd/csrc/gemm8p.hip, tile configuration 8) against a plain fp32 torch reference on
+bf16-rounded inputs: every epilogue, ragged M / N / K tails, row remaps, split-K, several tiles per workgroup (persistent
+stream across tiles) and the transposed (weight-gradient) form.  Same tolerance as tests/test_kernels_gpu.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import DEV, bf, check, interleave, ops  # noqa: F401  (same helpers / tolerance)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _force_cfg8():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vtp_amd import _lib
+    lib = _lib.load()
+    lib.vtp_set_gemm_tuning(8, 3)
+    yield
+    lib.vtp_set_gemm_tuning(-1, 3)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 344, 200), (8224, 2304, 768),
+                                   (1000, 64, 768), (64, 768, 72), (70000, 256, 128), (2500, 4096, 256)])
+def test_gemm8p_bias_bf16(M, N, K):
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + K)
+    a = bf(torch.randn(M, K, device=DEV, generator=g) + torch.linspace(-1, 1, M, device=DEV)[:, None])
+    b = bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    bias = torch.randn(N, device=DEV, generator=g)
+    c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for rep in range(2):  # a second launch must give the same result (no state carried between launches)
+        o.gemm_nt(a, b, c, bias=bias, epi=o.EPI_BF16)
+    ref = a.float() @ b.float().T + bias
+    check(c, ref, f"gemm8p bf16 {M}x{N}x{K}")
+
+
+def test_gemm8p_f32_residual_gamma_and_remaps():
+    o = ops()
+    B, hw, D, K = 9, 256, 384, 768
+    N_tok = hw + 1
+    g = torch.Generator(device=DEV).manual_seed(1)
+    a = bf(torch.randn(B * hw, K, device=DEV, generator=g))
+    w = bf(torch.randn(D, K, device=DEV, generator=g) * 0.05)
+    bias = torch.randn(D, device=DEV, generator=g)
+    gamma = torch.rand(D, device=DEV, generator=g) + 0.5
+    x = torch.randn(B * N_tok, D, device=DEV, generator=g)
+    x0 = x.clone()
+    o.gemm_nt(a, w, x, M=B * hw, bias=bias, gamma=gamma, resid=x, epi=o.EPI_F32, c_remap=(hw, 1))
+    ref = x0.clone().view(B, N_tok, D)
+    ref[:, 1:] += ((a.float() @ w.float().T + bias) * gamma).view(B, hw, D)
+    check(x, ref.view(-1, D), "gemm8p f32 resid+gamma+c_remap", bf16_out=False, scale=1e-5)
+    full = bf(torch.randn(B * N_tok, D, device=DEV, generator=g))
+    w2 = bf(torch.randn(64, D, device=DEV, generator=g) * 0.1)
+    out = torch.zeros(B * hw, 64, device=DEV)
+    o.gemm_nt(full, w2, out, M=B * hw, epi=o.EPI_F32, a_remap=(hw, 1))
+    ref2 = full.view(B, N_tok, D)[:, 1:].reshape(-1, D).float() @ w2.float().T
+    check(out, ref2, "gemm8p f32 a_remap", bf16_out=False, scale=1e-5)
+    out3 = torch.zeros(B, 64, device=DEV)
+    o.gemm_nt(full, w2, out3, M=B, lda=N_tok * D, epi=o.EPI_F32)
+    check(out3, full.view(B, N_tok, D)[:, 0].float() @ w2.float().T, "gemm8p f32 strided cls rows", bf16_out=False, scale=1e-5)
+
+
+@pytest.mark.parametrize("M,D,H", [(257, 128, 344), (2056, 768, 2048)])
+def test_gemm8p_swiglu(M, D, H):
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = bf(torch.randn(M, D, device=DEV, generator=g))
+    w1 = bf(torch.randn(H, D, device=DEV, generator=g) * 0.08)
+    w2 = bf(torch.randn(H, D, device=DEV, generator=g) * 0.08)
+    b1 = torch.randn(H, device=DEV, generator=g) * 0.1
+    b2 = torch.randn(H, device=DEV, generator=g) * 0.1
+    w12, b12 = interleave(w1, w2).contiguous(), interleave(b1, b2).contiguous()
+    hid = torch.full((M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    x12 = torch.full((M, 2 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.gemm_nt(x, w12, hid, N=2 * H, c2=x12, bias=b12, epi=o.EPI_SWIGLU)
+    x1 = bf(x.float() @ w1.float().T + b1)
+    x2 = bf(x.float() @ w2.float().T + b2)
+    ref = bf(F.silu(x1.float())).float() * x2.float()
+    check(hid, ref, f"gemm8p swiglu hidden {M}x{D}x{H}", scale=4e-3)
+    check(x12, interleave(x1.T.contiguous(), x2.T.contiguous()).T, "gemm8p swiglu x12")
+
+
+def test_gemm8p_gelu_slab_and_atomic_splitk():
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    M, N, K = 700, 512, 128
+    a = bf(torch.randn(M, K, device=DEV, generator=g))
+    w = bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    bias = torch.randn(N, device=DEV, generator=g) * 0.1
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    o.gemm_nt(a, w, out, c2=pre, bias=bias, epi=o.EPI_GELU)
+    p = bf(a.float() @ w.float().T + bias)
+    check(pre, p, "gemm8p gelu pre")
+    check(out, F.gelu(p.float()), "gemm8p gelu out", scale=4e-3)
+    N1, N2, Kb = 344, 128, 8224
+    A = bf(torch.randn(N1, Kb, device=DEV, generator=g))
+    Bm = bf(torch.randn(N2, Kb, device=DEV, generator=g))
+    C = torch.ones(N1, N2, device=DEV)
+    o.gemm_nt(A, Bm, C, epi=o.EPI_F32_ATOMIC, splits=7)
+    check(C, 1.0 + A.float() @ Bm.float().T, "gemm8p atomic split-K", bf16_out=False, scale=2e-5)
+    S = o.gemm_splits(Kb, 5)
+    slab = torch.full((S * N1 * N2,), float("nan"), device=DEV)
+    o.gemm_nt(A, Bm, slab, M=N1, N=N2, K=Kb, ldc=N2, ldc2=N1 * N2 // 4, epi=o.EPI_F32_SLAB, splits=S)
+    check(slab.view(S, -1).sum(0).view(N1, N2), A.float() @ Bm.float().T, "gemm8p slab split-K", bf16_out=False, scale=2e-5)
+
+
+@pytest.mark.parametrize("Mo,No,K,splits", [(256, 256, 64, 1), (768, 768, 8224, 11), (2304, 768, 8224, 4), (344, 128, 515, 1),
+                                            (64, 768, 8192, 3), (128, 688, 1000, 2), (4096, 768, 34144, 5)])
+def test_gemm8p_tn_matches_reference(Mo, No, K, splits):
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(Mo + No + K)
+    A = bf(torch.randn(K, Mo, device=DEV, generator=g) + torch.linspace(-1, 1, Mo, device=DEV)[None, :])
+    Bm = bf(torch.randn(K, No, device=DEV, generator=g))
+    ref = A.float().T @ Bm.float()
+    S = o.gemm_splits(K, splits)
+    if S == 1:
+        C = torch.ones(Mo, No, device=DEV)
+        o.gemm_tn(A, Bm, C, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, resid=C, epi=o.EPI_F32)
+        check(C, 1 + ref, f"gemm8p_tn {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)
+    else:
+        slab = torch.full((S * Mo * No,), float("nan"), device=DEV)
+        o.gemm_tn(A, Bm, slab, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, ldc2=Mo * No // 4, epi=o.EPI_F32_SLAB, splits=S)
+        C = torch.ones(Mo, No, device=DEV)
+        o.reduce_slabs(slab, Mo * No, S, C, Mo * No, accumulate=True)
+        check(C, 1 + ref, f"gemm8p_tn split {Mo}x{No}x{K} S={S}", bf16_out=False, scale=2e-5)
+
+
+def test_gemm8p_tn_swiglu_c_remap():
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    T, D, H = 1200, 128, 176
+    x = bf(torch.randn(T, D, device=DEV, generator=g))
+    dy = bf(torch.randn(T, 2 * H, device=DEV, generator=g))
+    C = torch.zeros(2 * H, D, device=DEV)
+    o.gemm_tn(dy, x, C, M=2 * H, N=D, K=T, lda=2 * H, ldb=D, ldc=D, resid=C, epi=o.EPI_F32, c_remap=(-1, H))
+    ref_i = dy.float().T @ x.float()
+    gi = torch.arange(2 * H, device=DEV)
+    dst = (gi // 16) * 8 + (gi % 8) + ((gi % 16) >= 8) * H
+    ref = torch.zeros_like(ref_i)
+    ref[dst] = ref_i
+    check(C, ref, "gemm8p_tn swiglu c_remap", bf16_out=False, scale=2e-5)

@@ -1,0 +1,307 @@
+// 256 x 256 x 64 "8-phase" bf16 MFMA GEMM main loop for gfx950 (CDNA4): the large-M GEMMs of the VTP train step
+// (row-concatenated trunk passes, M = 16k .. 34k tokens; weight gradients with K = tokens).  Same contract, operand layouts,
+// swizzles and epilogues (gemm_common.h) as gemm.hip; what differs is the schedule of the k loop.
+//
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 VGPRs); waves w and
+//     w + 4 share a SIMD and belong to different wave groups (group = w >> 2 = the wave's row half).
+//   * a k-tile (64 deep) is staged as FOUR 16-KiB half-tiles, in the order they are consumed:
+//       j = 0  B-first   columns  wc*64 + [0,32)   of every wave column wc      (4 ds_read_b128 per wave)
+//       j = 1  A-first   rows     wr*128 + [0,64)  of every wave row wr         (8 reads)
+//       j = 2  B-second  columns  wc*64 + [32,64)
+//       j = 3  A-second  rows     wr*128 + [64,128)
+//     NT image of a half-tile: [128 rows][64 k] (128-B rows, 16-B chunk index XOR ((row >> 1) & 7));
+//     TN image (weight gradients, operands [k = tokens][columns]): [64 k][128 cols] (256-B rows, chunk XOR 4 * (k & 3)), read
+//     with ds_read_b64_tr_b16.  Each wave issues 2 LDS-DMA pieces (global_load_lds_dwordx4, 1 KiB) per half-tile.
+//   * ring of 8 half-tile slots (2 k-tiles); the staging cursor runs 7 half-tiles ahead of the compute cursor, ACROSS output
+//     tiles (persistent workgroups: the next tile's operands stream in under the current tile's last k-tiles and epilogue).
+//   * one k-tile = 4 phases; phase p = { fragment reads of p | LDS-DMA issue of half-tile g + 7 | s_barrier | 8 MFMAs (one
+//     64 x 32 quadrant of the wave tile x k = 64) | s_barrier }.  The two wave groups run ONE barrier apart (group 1 executes
+//     one extra barrier in front of a tile's k loop, group 0 one behind it), so on every SIMD one wave is in its MFMA segment
+//     while its partner reads LDS / issues DMA: the matrix pipe is never shared and never idle for longer than a barrier.
+//   * `s_waitcnt vmcnt(6)` once per k-tile (phase 3): every half-tile of the next k-tile has landed, 3 stay in flight.
+//   Hazards (why the order j = B-first, A-first, B-second, A-second): the slot overwritten in phase p held the half-tile
+//   consumed >= 2 phases earlier, except B-first (consumed in phase 0, overwritten in phase 1): its four reads are issued
+//   first and retired by `lgkmcnt(8)` in front of phase 0's barrier.
+//   * dedicated 32 KiB epilogue staging (4 KiB per wave) beside the 128 KiB ring: 160 KiB = all of a CU's LDS, 1 workgroup / CU.
+#include "gemm_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace vtp {
+
+namespace {
+constexpr int P8_SLOT = 16384;
+constexpr int P8_RING = 8 * P8_SLOT;
+constexpr int P8_REGION = 4096;
+constexpr int P8_LDS = P8_RING + 8 * P8_REGION;
+}  // namespace
+
+__device__ __forceinline__ void p8_wait_vm_halftiles(int n) {  // at most n (0..3) half-tiles = 2 n DMA pieces outstanding
+  if (n >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, bool TRANS>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int hi = lane >> 5;
+
+  const int tiles_m = (p.M + 255) >> 8;
+  const int tiles_n = (p.N + 255) >> 8;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int n_my = (ntiles - (int)blockIdx.x + G - 1) / G;
+  auto tile_origin = [&](int i, int& m0, int& n0) {
+    int wg = blockIdx.x + i * G;
+    if (p.xcd_swizzle & 1) {  // bijective on [0, ntiles): XCD x owns a contiguous chunk of the tile list
+      const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
+      wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+    }
+    n0 = (wg % tiles_n) << 8;
+    m0 = (wg / tiles_n) << 8;
+  };
+  const int kbeg = blockIdx.z * p.k_split;
+  const int kend = min(p.K, kbeg + p.k_split);
+  const int nk = (kend - kbeg + 63) >> 6;
+  const int H = n_my * nk * 4;  // half-tiles this workgroup streams
+
+  // ---------------------------------------------------------------- staging (LDS-DMA) side
+  const char* zsrc = (const char*)g_zero_block;
+  const char* src[4][2];  // [half-tile type][piece]: per-lane source of k-tile 0 (null: column outside the matrix, TN only)
+  int kq[2];              // NT: this lane's k offset (elements) inside the k-tile | TN: its k row inside the k-tile
+  auto set_src = [&](int m0, int n0) {
+    if constexpr (!TRANS) {
+      const int prow = lane >> 3, slot = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + prow;  // row of the 128-row half-tile image
+        const int c = slot ^ ((r >> 1) & 7);
+        kq[i] = c * 8;
+        const int nb = n0 + (r >> 5) * 64 + (r & 31);
+        const int mb = m0 + (r >> 6) * 128 + (r & 63);
+        const int n1 = min(nb, p.N - 1), n2 = min(nb + 32, p.N - 1);
+        const int m1 = remap_row(min(mb, p.M - 1), p.a_grp, p.a_pre), m2 = remap_row(min(mb + 64, p.M - 1), p.a_grp, p.a_pre);
+        src[0][i] = (const char*)(p.B + (size_t)n1 * p.ldb + kbeg + c * 8);
+        src[2][i] = (const char*)(p.B + (size_t)n2 * p.ldb + kbeg + c * 8);
+        src[1][i] = (const char*)(p.A + (size_t)m1 * p.lda + kbeg + c * 8);
+        src[3][i] = (const char*)(p.A + (size_t)m2 * p.lda + kbeg + c * 8);
+      }
+    } else {
+      // piece q of a [64 k][128 cols] image: byte q*1024 + lane*16 -> k row r = q*4 + (lane >> 4), stored slot sp = lane & 15,
+      // source chunk s = sp ^ 4*(r & 3)
+      const int sp = lane & 15;
+      const int s = sp ^ (4 * ((lane >> 4) & 3));
+      const int cc = s * 8;  // column inside the 128-column image
+      const int nb = n0 + (cc >> 5) * 64 + (cc & 31);
+      const int mb = m0 + (cc >> 6) * 128 + (cc & 63);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 4 + (lane >> 4);
+        kq[i] = r;
+        const size_t ta = (size_t)(kbeg + r) * p.lda, tb = (size_t)(kbeg + r) * p.ldb;
+        src[0][i] = nb < p.N ? (const char*)(p.B + tb + nb) : nullptr;
+        src[2][i] = nb + 32 < p.N ? (const char*)(p.B + tb + nb + 32) : nullptr;
+        src[1][i] = mb < p.M ? (const char*)(p.A + ta + mb) : nullptr;
+        src[3][i] = mb + 64 < p.M ? (const char*)(p.A + ta + mb + 64) : nullptr;
+      }
+    }
+  };
+
+  int s_h = 0, s_i = 0, s_kt = 0;  // staging cursor: half-tile counter, my-tile index, k-tile inside that tile
+  auto issue = [&](auto jt) {       // half-tile type J == s_h & 3 (the call sites keep this invariant)
+    constexpr int J = decltype(jt)::value;
+    char* dst = smem + (s_h & 7) * P8_SLOT + wave * 2048;
+    const int krem = kend - kbeg - s_kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* s;
+      if constexpr (!TRANS) {
+        s = (kq[i] < krem) ? src[J][i] + (size_t)s_kt * 128 : zsrc;
+      } else {
+        const size_t ld = (J & 1) ? (size_t)p.lda : (size_t)p.ldb;
+        s = (kq[i] < krem && src[J][i]) ? src[J][i] + (size_t)s_kt * 128 * ld : zsrc;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+    ++s_h;
+    if constexpr (J == 3) {
+      if (++s_kt == nk) {
+        s_kt = 0;
+        if (++s_i < n_my) {
+          int m0s, n0s;
+          tile_origin(s_i, m0s, n0s);
+          set_src(m0s, n0s);
+        }
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // ---------------------------------------------------------------- fragment (LDS read) side
+  const int sw = (lane >> 1) & 7;
+  const int rowoff = (lane & 31) * 128;
+  const int t_li = lane & 15, t_rq = t_li >> 2, t_cin = ((lane >> 4) & 1) * 16 + (t_li & 3) * 4;
+  auto tr_frag = [&](const char* base, int colbase, int ks) -> bf16x8 {
+    const int col = colbase + t_cin;
+    const char* b0 = base + (ks * 16 + hi * 8 + t_rq) * 256 + (((col >> 3) ^ (4 * t_rq)) << 4) + ((col & 7) << 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)b0);
+    bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(b0 + 4 * 256));
+    return __builtin_shufflevector(lo, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto load_b = [&](const char* slot, bf16x8 (&f)[4]) {  // this wave's 32 columns of a B half-tile, k = 0..63
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (!TRANS) f[ks] = *(const bf16x8*)(slot + wc * 4096 + rowoff + (((2 * ks + hi) ^ sw) << 4));
+      else f[ks] = tr_frag(slot, wc * 32, ks);
+    }
+  };
+  auto load_a = [&](const char* slot, bf16x8 (&f)[2][4]) {  // this wave's 64 rows of an A half-tile
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (!TRANS) f[jj][ks] = *(const bf16x8*)(slot + wr * 8192 + jj * 4096 + rowoff + (((2 * ks + hi) ^ sw) << 4));
+        else f[jj][ks] = tr_frag(slot, wr * 64 + jj * 32, ks);
+      }
+  };
+
+  f32x16 acc[2][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+  auto mma2 = [&](f32x16& c0, f32x16& c1, const bf16x8 (&w)[4], const bf16x8 (&x0)[4], const bf16x8 (&x1)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x0[ks], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x1[ks], c1, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto seg_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---------------------------------------------------------------- prologue: 7 half-tiles in flight, the first 4 landed
+  {
+    int m0s, n0s;
+    tile_origin(0, m0s, n0s);
+    set_src(m0s, n0s);
+  }
+  if (s_h < H) issue(I0{});
+  if (s_h < H) issue(I1{});
+  if (s_h < H) issue(I2{});
+  if (s_h < H) issue(I3{});
+  if (s_h < H) issue(I0{});
+  if (s_h < H) issue(I1{});
+  if (s_h < H) issue(I2{});
+  p8_wait_vm_halftiles(s_h - 4);
+  seg_barrier();
+
+  int ktg = 0;  // k-tiles computed so far (across my tiles): ring half = ktg & 1
+  for (int ti = 0; ti < n_my; ++ti) {
+    int m0, n0;
+    tile_origin(ti, m0, n0);
+    if (wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
+    for (int kt = 0; kt < nk; ++kt, ++ktg) {
+      const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
+      bf16x8 b1[4], b2[4], a1[2][4], a2[2][4];
+      // ---- phase 0: B-first + A-first -> quadrant (cols 0..31, rows 0..63)
+      load_b(kb, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(kb + P8_SLOT, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_h < H) issue(I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B-first reads (issued first) are done: phase 1 overwrites that slot
+      seg_barrier();
+      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1]);
+      seg_barrier();
+      // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63)
+      load_b(kb + 2 * P8_SLOT, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_h < H) issue(I0{});
+      seg_barrier();
+      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
+      seg_barrier();
+      // ---- phase 2: A-second -> quadrant (cols 32..63, rows 64..127)
+      load_a(kb + 3 * P8_SLOT, a2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_h < H) issue(I1{});
+      seg_barrier();
+      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
+      seg_barrier();
+      // ---- phase 3: quadrant (cols 0..31, rows 64..127); the next k-tile's four half-tiles must have landed
+      if (s_h < H) issue(I2{});
+      p8_wait_vm_halftiles(s_h - 4 * (ktg + 2));
+      seg_barrier();
+      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
+      seg_barrier();
+    }
+    if (wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
+    char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
+    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane);
+    zero_acc();
+  }
+}
+
+template <int EPI, bool TRANS>
+static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
+  auto kern = gemm8p_kernel<EPI, TRANS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    attr_set = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    cus = prop.multiProcessorCount - prop.multiProcessorCount % 8;
+    if (cus < 8) cus = 8;
+  }
+  const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  dim3 grid(splits == 1 && ntiles > cus ? cus : ntiles, 1, splits);
+  hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS, s, a);
+  return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
+}
+
+// entry points used by the dispatchers of gemm.hip
+int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
+  switch (epi) {
+    case EPI_BF16: return launch8p<EPI_BF16, false>(a, 1, s);
+    case EPI_F32: return launch8p<EPI_F32, false>(a, 1, s);
+    case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false>(a, 1, s);
+    case EPI_GELU: return launch8p<EPI_GELU, false>(a, 1, s);
+    case EPI_F32_ATOMIC: return launch8p<EPI_F32_ATOMIC, false>(a, splits, s);
+    case EPI_F32_SLAB: return launch8p<EPI_F32_SLAB, false>(a, splits, s);
+    default: set_error("gemm8p: unsupported epilogue %d", epi); return VTP_ERR_ARG;
+  }
+}
+
+int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
+  if (epi == EPI_F32) return launch8p<EPI_F32, true>(a, 1, s);
+  return launch8p<EPI_F32_SLAB, true>(a, splits, s);
+}
+
+}  // namespace vtp

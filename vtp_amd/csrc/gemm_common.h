@@ -1,0 +1,311 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: ring / 2-barrier main loops; gemm8p.hip: 256x256 8-phase main loop):
+// the argument block, the row remaps and the fused epilogues.  Device code only.
+#pragma once
+#include "common.h"
+#include "vtp_hip.h"
+
+namespace vtp {
+
+// zero source block for K / row tails of the LDS-DMA staging (one copy per translation unit: device code is not linked across TUs)
+static __device__ __attribute__((aligned(16))) unsigned int g_zero_block[16] = {0};
+
+struct GemmArgs {
+  const bf16* A;   // [M, lda]
+  const bf16* B;   // [N, ldb]
+  void* C;         // bf16 or f32 [*, ldc]
+  void* C2;        // secondary output (SwiGLU: x12 pre-activations; GELU: pre-activation), may be null
+  const float* bias;   // [N] or null   (SwiGLU: interleaved [2H])
+  const float* gamma;  // [N] LayerScale or null
+  const float* resid;  // f32 [*, ldc] residual (EPI_F32 only) or null
+  int M, N, K;
+  int lda, ldb, ldc, ldc2;
+  int a_grp, a_pre;  // A row remap: row(m) = m + (m / a_grp + 1) * a_pre   (a_grp == 0: identity)
+  int c_grp, c_pre;  // C row remap (same formula; c_grp < 0: SwiGLU de-interleave)
+  int b_grp, b_pre;  // TRANS mode only: token-row remap of the B operand
+  int k_split;       // K elements per blockIdx.z slice (multiple of 64)
+  int xcd_swizzle;
+  float alpha;
+  // 3x3 convolution as an implicit GEMM over a zero-bordered NHWC image stack (vtp_conv3x3): A = [NB*(H+2)*(W+2), conv_cin]
+  // pixel rows, k-tile kt reads tap (kt*64)/conv_cin at row offset (ky-1)*conv_w2 + (kx-1).  conv_cin == 0: plain GEMM.
+  int conv_cin, conv_w2, conv_p, conv_h2;
+};
+
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
+       EPI_CONV_MASK = 7 };
+
+__device__ __forceinline__ int remap_row(int m, int grp, int pre) {
+  if (grp > 0) return m + (m / grp + 1) * pre;
+  if (grp < 0) return ((m >> 4) << 3) + (m & 7) + ((m & 8) ? pre : 0);  // SwiGLU de-interleave
+  return m;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// does the epilogue of this (EPI, shape) stage its output through the wave's private LDS region?  (wave-uniform; the caller
+// must make sure the region is free -- e.g. a barrier after the last fragment reads when the region aliases the operand ring)
+template <int EPI, bool TRANS, int WTN, int REGION>
+__device__ __forceinline__ bool gemm_epilogue_uses_lds(const GemmArgs& p) {
+  if constexpr (TRANS || WTN < 64) return false;
+  if constexpr (EPI == EPI_BF16) return (p.N & 7) == 0 && (p.xcd_swizzle & 2);
+  if constexpr (EPI == EPI_SWIGLU) return (p.xcd_swizzle & 2) && (p.N & 15) == 0;
+  if constexpr (EPI == EPI_F32) return REGION / 4096 == 1 && (p.xcd_swizzle & 2) && (p.N & 3) == 0;
+  return false;
+}
+
+// Epilogue of one wave: acc[i][j] = 32x32 fp32 tile (i over the wave's WTN / 32 column blocks, j over its WTM / 32 row blocks)
+// of the output tile at (m0, n0); the wave's sub-tile starts at row wm * WTM, column wn * WTN.  MFMA operands were swapped
+// (weight rows = A operand), so a lane holds, for output row m = .. + (lane & 31), columns nb + 8*q + 4*hi + (0..3), q = 0..3.
+// reg: this wave's private LDS staging region of REGION bytes (or null: direct stores).
+template <int EPI, bool TRANS, int WTM, int WTN, int REGION>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[WTN / 32][WTM / 32], char* reg, int m0, int n0,
+                                              int wm, int wn, int lane) {
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int hi = lane >> 5;
+  // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
+  // bf16 outputs go through LDS so that the global stores are full 128/256-B row segments (16 B per lane, consecutive lanes
+  // = consecutive addresses) instead of 8-B pieces of 32 different rows per instruction: each wave transposes 32-row
+  // blocks of its sub-tile in a private region of the ring slot the last k-tile occupied (XOR-swizzled 16-B chunks).
+  bool staged_out = false;
+  if constexpr (EPI == EPI_BF16 && WTN >= 64 && !TRANS) {
+    if (reg && (p.N & 7) == 0 && (p.xcd_swizzle & 2)) {
+      staged_out = true;
+      constexpr int RB = WTN * 2, CPR = RB / 16;
+      static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = i * 32 + 8 * q + 4 * hi, n = n0 + wn * WTN + nl;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+            if (p.bias && n < p.N) v += *(const f32x4*)(p.bias + n);
+            *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
+          }
+#pragma unroll
+        for (int t = 0; t < 32 * CPR / 64; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+          const bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+          const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+          if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_SWIGLU && WTN >= 64 && !TRANS) {
+    // SwiGLU: the pre-activations x12 (interleaved gemm columns, bf16) and the hidden activations (WTN/2 columns) both leave
+    // through LDS; the activation itself is computed lane-locally first (quads (q, q+1) = (w1, w2) columns)
+    if (reg && (p.xcd_swizzle & 2) && (p.N & 15) == 0) {
+      staged_out = true;
+      constexpr int RB = WTN * 2, CPR = RB / 16, RBH = WTN, CPRH = RBH / 16;
+      static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        bf16x4 hs[TN][2];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; q += 2) {
+            const int nl = i * 32 + 8 * q + 4 * hi, n1 = n0 + wn * WTN + nl;
+            f32x4 x1, x2, hsw;
+            const bool ok = n1 < p.N;
+            const f32x4 b1 = ok ? *(const f32x4*)(p.bias + n1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b2 = ok ? *(const f32x4*)(p.bias + n1 + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              x1[e] = acc[i][j][4 * q + e] + b1[e];
+              x2[e] = acc[i][j][4 * q + 4 + e] + b2[e];
+            }
+            const bf16x4 x1b = __builtin_convertvector(x1, bf16x4), x2b = __builtin_convertvector(x2, bf16x4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hsw[e] = bf2f(f2bf(silu_f(bf2f(x1b[e])))) * bf2f(x2b[e]);
+            hs[i][q >> 1] = __builtin_convertvector(hsw, bf16x4);
+            if (p.C2) {
+              *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = x1b;
+              *(bf16x4*)(reg + r * RB + ((((nl >> 3) + 1) ^ (r & (CPR - 1))) << 4) + hi * 8) = x2b;
+            }
+          }
+        if (p.C2) {
+#pragma unroll
+          for (int t = 0; t < 32 * CPR / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+            const bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+            const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+            if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C2 + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc2 + n) = val;
+          }
+        }
+        // hidden: local column (2i + q/2)*8 + 4hi of a [32][WTN/2] block
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+            *(bf16x4*)(reg + r * RBH + ((((2 * i + h2)) ^ (r & (CPRH - 1))) << 4) + hi * 8) = hs[i][h2];
+#pragma unroll
+        for (int t = 0; t < 32 * CPRH / 64; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPRH, c = idx % CPRH;
+          const bf16x8 val = *(const bf16x8*)(reg + rr * RBH + ((c ^ (rr & (CPRH - 1))) << 4));
+          const int m = m0 + wm * WTM + j * 32 + rr, jh = ((n0 + wn * WTN) >> 1) + c * 8;
+          if (m < p.M && 2 * jh < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + jh) = val;
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_F32 && WTN >= 64 && !TRANS && REGION / 4096 == 1) {  // measured: pays for the 8-wave
+    // 128x128 / 256x128 kernels (128-B staging rows); the 256-B-row variants of the 4-wave / 256x256 kernels lost 5-7 %
+    // fp32 residual epilogue: raw accumulators through LDS in column groups that fit the wave's region; bias / LayerScale /
+    // residual are applied after the read-back, where each lane owns 4 consecutive columns of one row (coalesced resid loads)
+    if (reg && (p.xcd_swizzle & 2) && (p.N & 3) == 0) {
+      staged_out = true;
+      constexpr int IG = (REGION / 4096 >= TN) ? TN : (REGION / 4096);   // 32-column blocks per pass (32 rows x 128 B each)
+      static_assert(IG >= 1 && TN % IG == 0, "bad column grouping");
+      constexpr int RB = IG * 128, CPR = RB / 16;
+      const int r = lane & 31;
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int ig = 0; ig < TN / IG; ++ig) {
+#pragma unroll
+          for (int ii = 0; ii < IG; ++ii)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[ig * IG + ii][j][4 * q + e] * p.alpha;
+              *(f32x4*)(reg + r * RB + (((ii * 8 + 2 * q + hi) ^ (r & (CPR - 1))) << 4)) = v;
+            }
+#pragma unroll
+          for (int t = 0; t < 32 * CPR / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+            f32x4 v = *(const f32x4*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+            const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + ig * IG * 32 + c * 4;
+            if (m < p.M && n < p.N) {
+              const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
+              if (p.bias) v += *(const f32x4*)(p.bias + n);
+              if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
+              if (p.resid) v += *(const f32x4*)(p.resid + off);
+              *(f32x4*)((float*)p.C + off) = v;
+            }
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    if (staged_out) break;
+    const int m = m0 + wm * WTM + j * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    const int mc = remap_row(m, p.c_grp, p.c_pre);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n0 + wn * WTN + i * 32 + 4 * hi;
+      if constexpr (EPI == EPI_SWIGLU) {
+        // interleaved weight rows: 16-row groups = [8 rows of w1 | 8 rows of w2]; quads (0,1) and (2,3) pair up.
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          const int n1 = nb + 8 * q;  // gemm column of the w1 quad; w2 quad is n1 + 8
+          if (n1 >= p.N) continue;
+          f32x4 b1 = *(const f32x4*)(p.bias + n1);
+          f32x4 b2 = *(const f32x4*)(p.bias + n1 + 8);
+          f32x4 x1, x2, hsw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x1[e] = acc[i][j][4 * q + e] + b1[e];
+            x2[e] = acc[i][j][4 * q + 4 + e] + b2[e];
+          }
+          bf16x4 x1b = __builtin_convertvector(x1, bf16x4), x2b = __builtin_convertvector(x2, bf16x4);
+          if (p.C2) {
+            bf16* c2 = (bf16*)p.C2 + (size_t)mc * p.ldc2;
+            *(bf16x4*)(c2 + n1) = x1b;
+            *(bf16x4*)(c2 + n1 + 8) = x2b;
+          }
+          // match the eager bf16 rounding points of the reference: silu(bf16 x1) -> bf16, * bf16 x2 -> bf16
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float s = bf2f(f2bf(silu_f(bf2f(x1b[e]))));
+            hsw[e] = s * bf2f(x2b[e]);
+          }
+          const int jh = (n1 >> 4) * 8 + (n1 & 7);  // hidden column
+          *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + jh) = __builtin_convertvector(hsw, bf16x4);
+        }
+      } else if constexpr (EPI == EPI_CONV_RELU || EPI == EPI_CONV_MASK) {
+        // pixel row m of the zero-bordered stack: border rows are written as zeros so the next layer's taps read padding
+        const int r = m % p.conv_p, yy = r / p.conv_w2, xx = r - yy * p.conv_w2;
+        const bool border = yy == 0 || yy == p.conv_h2 - 1 || xx == 0 || xx == p.conv_w2 - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+          if constexpr (EPI == EPI_CONV_RELU) {
+            f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = border ? 0.f : fmaxf(v[e] + b[e], 0.f);
+          } else {  // input gradient: ReLU mask of the layer input (C2 = that activation; null = no ReLU in front)
+            if (p.C2) {
+              bf16x4 a = *(const bf16x4*)((const bf16*)p.C2 + (size_t)mc * p.ldc2 + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = bf2f(a[e]) > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = border ? 0.f : v[e];
+          }
+          *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + n) = __builtin_convertvector(v, bf16x4);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+          if constexpr (EPI == EPI_F32_ATOMIC) {
+            float* c = (float*)p.C + (size_t)mc * p.ldc + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + e, v[e]);
+          } else if constexpr (EPI == EPI_F32_SLAB) {
+            // split-K partial: slice z writes its own [rows, ldc] slab with plain 16-B stores (no atomics);
+            // vtp_reduce_slabs sums the slabs afterwards.  slab stride (in float4 units) travels in ldc2.
+            *(f32x4*)((float*)p.C + (size_t)blockIdx.z * (size_t)p.ldc2 * 4 + (size_t)mc * p.ldc + n) = v;
+          } else {
+            if (p.bias) {
+              f32x4 b = *(const f32x4*)(p.bias + n);
+              v += b;
+            }
+            if constexpr (EPI == EPI_BF16) {
+              *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + n) = __builtin_convertvector(v, bf16x4);
+            } else if constexpr (EPI == EPI_GELU) {
+              bf16x4 pre = __builtin_convertvector(v, bf16x4);
+              if (p.C2) *(bf16x4*)((bf16*)p.C2 + (size_t)mc * p.ldc2 + n) = pre;
+              f32x4 g;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[e] = gelu_erf(bf2f(pre[e]));
+              *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + n) = __builtin_convertvector(g, bf16x4);
+            } else {  // EPI_F32: out = resid + gamma * (acc + bias)
+              if (p.gamma) {
+                f32x4 g = *(const f32x4*)(p.gamma + n);
+                v *= g;
+              }
+              if (p.resid) {
+                f32x4 r = *(const f32x4*)(p.resid + (size_t)mc * p.ldc + n);
+                v += r;
+              }
+              *(f32x4*)((float*)p.C + (size_t)mc * p.ldc + n) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace vtp
