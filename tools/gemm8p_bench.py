@@ -43,13 +43,18 @@ def timeit(fns, rounds=7, iters=10):
 
 
 def main():
-    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "var")
+    var = len(sys.argv) > 1 and sys.argv[1] == "var"   # schedule-variant sweep (VTP_GEMM8P_VAR): bf16-output NT + slab TN only
+    if var:
+        print(f"VTP_GEMM8P_VAR={os.environ.get('VTP_GEMM8P_VAR', '0')}", flush=True)
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     Ms = [34144] if quick else [34144, 16448, 8224]
     for M in Ms:
         for tag, N, K, epi in LAYER:
+            if var and epi != ops.EPI_BF16:
+                continue
             a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
             b = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
             bias = torch.randn(N, device=dev, generator=g)

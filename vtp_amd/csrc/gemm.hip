@@ -362,15 +362,17 @@ static int swz_flags() {
 // gemm8p.hip: 256x256 8-phase main loop (cfg 8)
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s);
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s);
+bool gemm8p_fits(const GemmArgs& a, bool trans);
 
 template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
   if (cfg == 8) {
     if constexpr (TRANS) {
-      if (a.a_grp == 0 && a.b_grp == 0) return launch_gemm8p_tn(a, EPI, splits, s);
+      if (a.a_grp == 0 && a.b_grp == 0 && gemm8p_fits(a, true)) return launch_gemm8p_tn(a, EPI, splits, s);
       cfg = 5;  // token-row remaps (patch-embed / bottleneck wgrads): the ring kernel
     } else if constexpr (EPI != EPI_CONV_RELU && EPI != EPI_CONV_MASK) {
-      return launch_gemm8p_nt(a, EPI, splits, s);
+      if (gemm8p_fits(a, false)) return launch_gemm8p_nt(a, EPI, splits, s);
+      cfg = 5;
     }
   }
   if constexpr (TRANS) {  // weight-gradient shapes only: keep the instantiation count small

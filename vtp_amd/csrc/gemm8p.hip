@@ -43,8 +43,22 @@ __device__ __forceinline__ void p8_wait_vm_halftiles(int n) {  // at most n (0..
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, bool TRANS>
+// VAR (experiment switches, 0 = shipped schedule): bit 0 = no group stagger | bit 1 = no s_setprio around the MFMA segments |
+// bit 2 = LDS-DMA pieces issued between the MFMAs of the segment instead of in the load segment
+// LDS-DMA of 16 B per lane with a scalar 64-bit base + a 32-bit lane offset (no vector address arithmetic), M0 = LDS
+// destination of the wave's 1-KiB piece.  Inline asm because hipcc turns the "tail or not" choice of the source pointer into a
+// per-lane 64-bit select in front of every piece otherwise; its completion is counted by hand (the vmcnt waits below).
+__device__ __forceinline__ void p8_glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+template <int EPI, bool TRANS, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+  constexpr bool STAGGER = !(VAR & 1), SETPRIO = !(VAR & 2), DMA_IN_MMA = (VAR & 4) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,8 +87,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 
   // ---------------------------------------------------------------- staging (LDS-DMA) side
   const char* zsrc = (const char*)g_zero_block;
-  const char* src[4][2];  // [half-tile type][piece]: per-lane source of k-tile 0 (null: column outside the matrix, TN only)
-  int kq[2];              // NT: this lane's k offset (elements) inside the k-tile | TN: its k row inside the k-tile
+  // per-lane byte offsets (k-tile 0) from the matrix base -- B for half-tile types 0 / 2, A for 1 / 3; rows (NT) and columns
+  // (TN) beyond the matrix are clamped to valid ones: they only feed output rows / columns that the epilogue masks
+  unsigned off[4][2];
+  int kq[2];  // NT: this lane's k offset (elements) inside the k-tile | TN: its k row inside the k-tile
   auto set_src = [&](int m0, int n0) {
     if constexpr (!TRANS) {
       const int prow = lane >> 3, slot = lane & 7;
@@ -87,10 +103,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         const int mb = m0 + (r >> 6) * 128 + (r & 63);
         const int n1 = min(nb, p.N - 1), n2 = min(nb + 32, p.N - 1);
         const int m1 = remap_row(min(mb, p.M - 1), p.a_grp, p.a_pre), m2 = remap_row(min(mb + 64, p.M - 1), p.a_grp, p.a_pre);
-        src[0][i] = (const char*)(p.B + (size_t)n1 * p.ldb + kbeg + c * 8);
-        src[2][i] = (const char*)(p.B + (size_t)n2 * p.ldb + kbeg + c * 8);
-        src[1][i] = (const char*)(p.A + (size_t)m1 * p.lda + kbeg + c * 8);
-        src[3][i] = (const char*)(p.A + (size_t)m2 * p.lda + kbeg + c * 8);
+        off[0][i] = (unsigned)(((size_t)n1 * p.ldb + kbeg + c * 8) * 2);
+        off[2][i] = (unsigned)(((size_t)n2 * p.ldb + kbeg + c * 8) * 2);
+        off[1][i] = (unsigned)(((size_t)m1 * p.lda + kbeg + c * 8) * 2);
+        off[3][i] = (unsigned)(((size_t)m2 * p.lda + kbeg + c * 8) * 2);
       }
     } else {
       // piece q of a [64 k][128 cols] image: byte q*1024 + lane*16 -> k row r = q*4 + (lane >> 4), stored slot sp = lane & 15,
@@ -100,47 +116,73 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       const int cc = s * 8;  // column inside the 128-column image
       const int nb = n0 + (cc >> 5) * 64 + (cc & 31);
       const int mb = m0 + (cc >> 6) * 128 + (cc & 63);
+      const int n1 = min(nb, p.N - 8), n2 = min(nb + 32, p.N - 8), m1 = min(mb, p.M - 8), m2 = min(mb + 64, p.M - 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 4 + (lane >> 4);
         kq[i] = r;
         const size_t ta = (size_t)(kbeg + r) * p.lda, tb = (size_t)(kbeg + r) * p.ldb;
-        src[0][i] = nb < p.N ? (const char*)(p.B + tb + nb) : nullptr;
-        src[2][i] = nb + 32 < p.N ? (const char*)(p.B + tb + nb + 32) : nullptr;
-        src[1][i] = mb < p.M ? (const char*)(p.A + ta + mb) : nullptr;
-        src[3][i] = mb + 64 < p.M ? (const char*)(p.A + ta + mb + 64) : nullptr;
+        off[0][i] = (unsigned)((tb + n1) * 2);
+        off[2][i] = (unsigned)((tb + n2) * 2);
+        off[1][i] = (unsigned)((ta + m1) * 2);
+        off[3][i] = (unsigned)((ta + m2) * 2);
       }
     }
   };
 
-  int s_h = 0, s_i = 0, s_kt = 0;  // staging cursor: half-tile counter, my-tile index, k-tile inside that tile
-  auto issue = [&](auto jt) {       // half-tile type J == s_h & 3 (the call sites keep this invariant)
+  // staging cursor -- all wave-uniform (SGPRs), updated incrementally so that the load segment of a phase carries a handful
+  // of scalar instructions: half-tile counter, my-tile index, k-tile inside that tile, LDS destination of this wave's piece 0
+  // of the half-tile under the cursor, the operand bases advanced to the cursor's k-tile, "no K tail in this k-tile"
+  int s_h = 0, s_i = 0, s_kt = 0;
+  unsigned s_dst = (unsigned)(size_t)smem + wave * 2048;
+  const size_t step_a = TRANS ? (size_t)128 * p.lda : 128, step_b = TRANS ? (size_t)128 * p.ldb : 128;
+  const char* s_pa = (const char*)p.A;
+  const char* s_pb = (const char*)p.B;
+  bool s_fast = kend - kbeg >= 64;
+  // one 1-KiB LDS-DMA piece (i = 0, 1) of the half-tile under the cursor; its type J == s_h & 3 (the call sites keep this invariant)
+  auto issue_piece = [&](auto jt, int i) {
     constexpr int J = decltype(jt)::value;
-    char* dst = smem + (s_h & 7) * P8_SLOT + wave * 2048;
-    const int krem = kend - kbeg - s_kt * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const char* s;
-      if constexpr (!TRANS) {
-        s = (kq[i] < krem) ? src[J][i] + (size_t)s_kt * 128 : zsrc;
-      } else {
-        const size_t ld = (J & 1) ? (size_t)p.lda : (size_t)p.ldb;
-        s = (kq[i] < krem && src[J][i]) ? src[J][i] + (size_t)s_kt * 128 * ld : zsrc;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    const char* base = (J & 1) ? s_pa : s_pb;
+    if (s_fast) {
+      p8_glds16(base, off[J][i], s_dst + i * 1024);
+    } else {  // K tail (the last k-tile of a tile only): zero-fill per lane
+      const int krem = kend - kbeg - s_kt * 64;
+      const char* z = (kq[i] < krem) ? base + off[J][i] : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)z,
+                                       (__attribute__((address_space(3))) void*)(size_t)(s_dst + i * 1024), 16, 0, 0);
     }
+  };
+  auto advance = [&](auto jt) {
+    constexpr int J = decltype(jt)::value;
     ++s_h;
+    s_dst = (s_dst + P8_SLOT) & (P8_RING - 1);  // the ring starts at LDS address 0 (the dynamic segment is the only LDS)
     if constexpr (J == 3) {
+      s_pa += step_a;
+      s_pb += step_b;
       if (++s_kt == nk) {
         s_kt = 0;
+        s_pa = (const char*)p.A;
+        s_pb = (const char*)p.B;
         if (++s_i < n_my) {
           int m0s, n0s;
           tile_origin(s_i, m0s, n0s);
           set_src(m0s, n0s);
         }
       }
+      s_fast = kend - kbeg - s_kt * 64 >= 64;
     }
+  };
+  auto issue = [&](auto jt) {
+    constexpr int J = decltype(jt)::value;
+    if (__builtin_expect(s_fast, 1)) {  // straight-line: 2 x { m0 = LDS destination ; global_load_lds scalar-base + lane offset }
+      const char* base = (J & 1) ? s_pa : s_pb;
+      p8_glds16(base, off[J][0], s_dst);
+      p8_glds16(base, off[J][1], s_dst + 1024);
+    } else {
+      issue_piece(jt, 0);
+      issue_piece(jt, 1);
+    }
+    advance(jt);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -185,14 +227,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
   zero_acc();
-  auto mma2 = [&](f32x16& c0, f32x16& c1, const bf16x8 (&w)[4], const bf16x8 (&x0)[4], const bf16x8 (&x1)[4]) {
-    __builtin_amdgcn_s_setprio(1);
+  // one MFMA segment: a 64 x 32 quadrant x k = 64.  jt: with DMA_IN_MMA the two LDS-DMA pieces of the half-tile under the
+  // staging cursor are issued behind the 2nd and the 6th MFMA (their issue cost hides under the matrix pipe)
+  auto mma2 = [&](f32x16& c0, f32x16& c1, const bf16x8 (&w)[4], const bf16x8 (&x0)[4], const bf16x8 (&x1)[4], auto jt) {
+    const bool dma = DMA_IN_MMA && s_h < H;
+    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x0[ks], c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x1[ks], c1, 0, 0, 0);
+      if constexpr (DMA_IN_MMA) {
+        if (ks == 0 || ks == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (dma) issue_piece(jt, ks >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (DMA_IN_MMA) {
+      if (dma) advance(jt);
+    }
   };
   auto seg_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
     tile_origin(ti, m0, n0);
-    if (wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
+    if (STAGGER && wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       bf16x8 b1[4], b2[4], a1[2][4], a2[2][4];
@@ -229,43 +284,45 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       load_a(kb + P8_SLOT, a1);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I3{});
+      if (!DMA_IN_MMA && s_h < H) issue(I3{});
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B-first reads (issued first) are done: phase 1 overwrites that slot
+      // the B-first reads (issued first) are done: phase 1 overwrites that slot (TN: 8 + 16 tr reads, the counter holds 15)
+      if constexpr (!TRANS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
       seg_barrier();
-      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1]);
+      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1], I3{});
       seg_barrier();
       // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63)
       load_b(kb + 2 * P8_SLOT, b2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I0{});
+      if (!DMA_IN_MMA && s_h < H) issue(I0{});
       seg_barrier();
-      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
+      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1], I0{});
       seg_barrier();
       // ---- phase 2: A-second -> quadrant (cols 32..63, rows 64..127)
       load_a(kb + 3 * P8_SLOT, a2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I1{});
+      if (!DMA_IN_MMA && s_h < H) issue(I1{});
       seg_barrier();
-      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
+      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1], I1{});
       seg_barrier();
       // ---- phase 3: quadrant (cols 0..31, rows 64..127); the next k-tile's four half-tiles must have landed
-      if (s_h < H) issue(I2{});
+      if (!DMA_IN_MMA && s_h < H) issue(I2{});
       p8_wait_vm_halftiles(s_h - 4 * (ktg + 2));
       seg_barrier();
-      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
+      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1], I2{});
       seg_barrier();
     }
-    if (wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
+    if (STAGGER && wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
     gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane);
     zero_acc();
   }
 }
 
-template <int EPI, bool TRANS>
+template <int EPI, bool TRANS, int VAR = 0>
 static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
-  auto kern = gemm8p_kernel<EPI, TRANS>;
+  auto kern = gemm8p_kernel<EPI, TRANS, VAR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
@@ -286,10 +343,28 @@ static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
   return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
 }
 
+// the staging addresses are 32-bit byte offsets from the operand bases
+bool gemm8p_fits(const GemmArgs& a, bool trans) {
+  const size_t lim = (size_t)1 << 32;
+  if (trans) return (size_t)a.K * a.lda * 2 < lim && (size_t)a.K * a.ldb * 2 < lim;
+  size_t rows_a = a.M;
+  if (a.a_grp > 0) rows_a += ((size_t)a.M / a.a_grp + 1) * a.a_pre;
+  return rows_a * a.lda * 2 < lim && (size_t)a.N * a.ldb * 2 < lim;
+}
+
 // entry points used by the dispatchers of gemm.hip
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: return launch8p<EPI_BF16, false>(a, 1, s);
+    case EPI_BF16: {
+      static const int var = getenv("VTP_GEMM8P_VAR") ? atoi(getenv("VTP_GEMM8P_VAR")) : 0;  // schedule experiments (tools/)
+      switch (var) {
+        case 1: return launch8p<EPI_BF16, false, 1>(a, 1, s);
+        case 2: return launch8p<EPI_BF16, false, 2>(a, 1, s);
+        case 4: return launch8p<EPI_BF16, false, 4>(a, 1, s);
+        case 6: return launch8p<EPI_BF16, false, 6>(a, 1, s);
+        default: return launch8p<EPI_BF16, false>(a, 1, s);
+      }
+    }
     case EPI_F32: return launch8p<EPI_F32, false>(a, 1, s);
     case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false>(a, 1, s);
     case EPI_GELU: return launch8p<EPI_GELU, false>(a, 1, s);
@@ -301,6 +376,8 @@ int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   if (epi == EPI_F32) return launch8p<EPI_F32, true>(a, 1, s);
+  static const int var = getenv("VTP_GEMM8P_VAR") ? atoi(getenv("VTP_GEMM8P_VAR")) : 0;
+  if (var == 4) return launch8p<EPI_F32_SLAB, true, 4>(a, splits, s);
   return launch8p<EPI_F32_SLAB, true>(a, splits, s);
 }
 
