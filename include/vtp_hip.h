@@ -46,6 +46,9 @@ const char* vtp_last_error(void);
  */
 enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4, VTP_EPI_F32_SLAB = 5 };
 int vtp_gemm_splits(int K, int splits);
+/* split-K factor the weight-gradient GEMM C[M,N] = A[K,M]^T B[K,N] should be launched with (tile configuration aware:
+ * 256x256 8-phase kernel -> tiles x splits = one round of the CUs; ring kernel -> just under 512 workgroups) */
+int vtp_gemm_tn_splits(int M, int N, int K);
 /* C[M,N] f32 = A[K,M]^T * B[K,N]: A, B bf16 row-major with the reduction dimension (tokens) as ROWS -- the weight-gradient
  * GEMM dW = dY^T X of every linear, read straight from the activation layouts (fragments are formed with the gfx950 LDS
  * transpose read; no transposed copies).  epilogue VTP_EPI_F32 (C = resid + acc, pass resid = C to accumulate) or

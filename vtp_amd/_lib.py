@@ -33,6 +33,7 @@ SIGNATURES = {
     "vtp_adamw_dev": [_P, _P, _P, _P, _P, _L, _P, _P],
     "vtp_reduce_slabs": [_P, _L, _I, _P, _L, _I, _P],
     "vtp_gemm_splits": [_I, _I],
+    "vtp_gemm_tn_splits": [_I, _I, _I],
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],

@@ -400,11 +400,38 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
   }
 }
 
+// the 256x256 8-phase kernel (cfg 8, gemm8p.hip; one workgroup per CU) wins when its tile list fills whole rounds of the 256
+// CUs: measured on MI355X (tools/gemm8p_bench.py, profiles/r02_gemm8p_bench.log) at M = 34144 / 16448 / 8224 rows
+static bool use_8p_nt(int M, int N, int K, int epilogue) {
+  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;  // 0: never (A/B runs)
+  if (!mode || N < 256 || K < 512) return false;
+  const int tiles = cdiv(M, 256) * cdiv(N, 256);
+  const int rounds = cdiv(tiles, 256);
+  const bool fills = tiles >= 192 && 4 * tiles >= 3 * rounds * 256;  // >= 75 % of the CU-rounds it occupies
+  switch (epilogue) {
+    case VTP_EPI_F32: return fills && K >= 2048;  // fp32 residual epilogue: HBM-bound at K = 768, the ring kernels overlap it better
+    case VTP_EPI_SWIGLU: return fills || tiles >= 512;
+    case VTP_EPI_BF16:
+    case VTP_EPI_GELU: return fills;
+    default: return false;
+  }
+}
+
+// weight gradients (TN, K = tokens): 8-phase kernel when tiles x splits is one round of the CUs and every K slice keeps >= 16
+// k-tiles (vtp_gemm_tn_splits picks the split factor accordingly)
+static bool use_8p_tn(int M, int N, int K, int splits, const GemmArgs& a) {
+  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;
+  if (!mode || a.a_grp || a.b_grp) return false;
+  const int wgs = cdiv(M, 256) * cdiv(N, 256) * splits;
+  return wgs >= 160 && wgs <= 256 && K / splits >= 1024;
+}
+
 // measured on MI355X at the VTP-B train-step shapes (tools/gemm_bench.py, profiles/gemm_bench_r01.log)
 static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (M < 128 || N < 128) return 0;
   if (splits > 1) return 3;                     // split-K wgrad: long K, few tiles -> 256x128, 3 stages
+  if (use_8p_nt(M, N, K, epilogue)) return 8;
   // big-M GEMMs (the row-concatenated list forward, M = 34k): 256x256 tiles halve the LDS / L2 traffic per flop; they
   // need >= 1.5 resident waves of tiles to beat the 128x128 kernels' finer quantisation (tools/gemm_bench.py 34144)
   static const int big_tiles = getenv("VTP_GEMM_BIG_TILES") ? atoi(getenv("VTP_GEMM_BIG_TILES")) : 384;
@@ -450,6 +477,26 @@ extern "C" int vtp_gemm_splits(int K, int splits) {
   if (splits < 1) splits = 1;
   const int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   return (K + ks - 1) / ks;
+}
+
+// split-K factor for a weight-gradient GEMM C[M,N] = A[K,M]^T B[K,N] (K = tokens): prefers the 8-phase kernel's operating point
+// (256x256 tiles x splits = one round of the CUs, >= 16 k-tiles per slice), else the ring kernel's (128x128 tiles x splits just
+// under one resident wave of 512 workgroups, >= 8 k-tiles per slice).  Returns the effective number of slices.
+extern "C" int vtp_gemm_tn_splits(int M, int N, int K) {
+  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;
+  const int t256 = cdiv(M, 256) * cdiv(N, 256);
+  int s8 = 256 / t256;
+  if (s8 > K / 1024) s8 = K / 1024;
+  if (mode && g_force_cfg < 0 && s8 >= 1) {
+    const int eff = vtp_gemm_splits(K, s8);
+    if (t256 * eff >= 160 && t256 * eff <= 256 && K / eff >= 1024) return eff;
+  }
+  const int t128 = cdiv(M, 128) * cdiv(N, 128);
+  int s = 512 / t128;
+  if (s > K / 512) s = K / 512;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return vtp_gemm_splits(K, s);
 }
 
 extern "C" int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle) {
@@ -516,7 +563,7 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
   // tools/gemm_tn_bench.py on MI355X: the 8-wave 128x128 tile wins on every wgrad shape (transpose reads want more waves)
-  int cfg = g_force_cfg >= 0 ? g_force_cfg : 5;
+  int cfg = g_force_cfg >= 0 ? g_force_cfg : (use_8p_tn(M, N, K, splits, a) ? 8 : 5);
   if (cfg != 2 && cfg != 3 && cfg != 5 && cfg != 8 && cfg != 16 && cfg != 21) cfg = 0;
   hipStream_t s = (hipStream_t)stream;
   if (epilogue == VTP_EPI_F32) return launch_gemm<EPI_F32, true>(a, 1, cfg, s);

@@ -289,7 +289,7 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
                 ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
             kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap,
                       c_remap=c_remap)
-            St = ops.gemm_splits(M, _wgrad_splits(N, K, M))
+            St = ops.gemm_tn_splits(N, K, M)  # tile-configuration aware (8-phase 256x256 kernel: tiles x splits = 256 CUs)
             if St == 1:
                 ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)
             else:

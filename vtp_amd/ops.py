@@ -143,6 +143,10 @@ def gemm_splits(K, splits):
     return _lib_().vtp_gemm_splits(K, splits)
 
 
+def gemm_tn_splits(M, N, K):
+    return _lib_().vtp_gemm_tn_splits(M, N, K)
+
+
 def reduce_slabs(slabs, stride, S, dst, n, accumulate=True):
     _lib.check(_lib_().vtp_reduce_slabs(_p(slabs), stride, S, _p(dst), n, int(accumulate), _s()), "vtp_reduce_slabs")
 
