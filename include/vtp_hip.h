@@ -62,6 +62,14 @@ int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);
 
+/* qkv projection with apply_rope fused into the epilogue: replaces attention.py:115 (qkv Linear) + attention.py:70-89
+ * (cast to the rope dtype, rotate the patch rows of q and k, cast back; bit-identical to vtp_gemm_nt + vtp_rope_qk).
+ * C bf16 [M, N = 3*D] = A[M,K] W[N,K]^T + bias; columns < rope_cols (= 2*D) of row m are rotated with row rope_pos[m] of the
+ * bf16 tables sin / cos [*, 64] (rope_pos[m] < 0: prefix (cls) rows, untouched).  rope_pos lets several images / resolutions
+ * share one launch (the list forward, vision_transformer.py:221-258): it indexes a concatenation of the per-resolution tables. */
+int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* C, int ldc, int M, int N, int K,
+                      const int* rope_pos, const void* rope_sin, const void* rope_cos, int rope_cols, void* stream);
+
 /* ---- normalisation ---------------------------------------------------------------------------
  * kind 0 = RMSNorm (normalization.py:17-22, eps 1e-5, no bias), 1 = LayerNorm (vision_transformer.py:30-34
  * eps 1e-6 decoder; normalization.py:25-31 text).  x f32 [M, D] -> y bf16 [M, D]; stats f32 [M,2] = (mean, rstd).

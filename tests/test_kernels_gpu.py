@@ -556,3 +556,43 @@ def test_gemm_tn_remaps_and_colsum():
     cs2 = torch.zeros(D, device=DEV)
     o.colsum_bf16(full, D, cs2, B * hw, D, in_remap=(hw, 1))
     check(cs2, patches.sum(0), "colsum in_remap", bf16_out=False, scale=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------- fused qkv + RoPE
+@pytest.mark.parametrize("cfg", [-1, 0, 4, 5, 8])
+def test_gemm_qkv_rope_bit_identical_to_gemm_then_rope(cfg):
+    """vtp_gemm_qkv_rope (apply_rope in the GEMM epilogue; list forward: two resolutions + cls prefix in ONE launch) must be
+    bit-identical to vtp_gemm_nt followed by vtp_rope_qk per segment -- for every tile configuration that can run it."""
+    from vtp_amd import _lib
+    from vtp_amd.engine import rope_tables
+    o = ops()
+    lib = _lib.load()
+    heads, D = 4, 256
+    segs = [(3, 16, 16), (5, 6, 6), (2, 16, 16)]  # (images, h, w): N = 1 + h*w tokens each
+    per = (100.0 ** (2 * torch.arange(16, dtype=torch.bfloat16) / 32))
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M = sum(b * (1 + h * w) for b, h, w in segs)
+    xn = bf(torch.randn(M, D, device=DEV, generator=g))
+    w = bf(torch.randn(3 * D, D, device=DEV, generator=g) * 0.1)
+    bias = torch.randn(3 * D, device=DEV, generator=g)
+    lib.vtp_set_gemm_tuning(cfg, 3)
+    try:
+        ref = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=DEV)
+        o.gemm_nt(xn, w, ref, M=M, N=3 * D, K=D, bias=bias, epi=o.EPI_BF16)
+        pos, ts, tc, r0, base = [], [], [], 0, 0
+        for b, h, wd in segs:
+            sin, cos = rope_tables(per, h, wd, torch.device(DEV))
+            N = 1 + h * wd
+            o.rope_qk(ref[r0:r0 + b * N], sin, cos, b, N, heads, 1)
+            pos.append(torch.cat([torch.tensor([-1], dtype=torch.int32), torch.arange(h * wd, dtype=torch.int32) + base]).repeat(b))
+            ts.append(sin)
+            tc.append(cos)
+            r0 += b * N
+            base += h * wd
+        out = torch.full((M, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        o.gemm_qkv_rope(xn, w, bias, out, M, 3 * D, D, torch.cat(pos).to(DEV), torch.cat(ts).contiguous(), torch.cat(tc).contiguous(),
+                        2 * D)
+    finally:
+        lib.vtp_set_gemm_tuning(-1, 3)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
+        f"cfg {cfg}: {int((out.view(torch.int16) != ref.view(torch.int16)).sum())} elements differ"

@@ -5,7 +5,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvtp_hip.so")
+LIB_PATH = os.environ.get("VTP_HIP_LIB") or os.path.join(_HERE, "lib", "libvtp_hip.so")  # override: A/B runs of two builds
 
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 
@@ -34,6 +34,7 @@ SIGNATURES = {
     "vtp_reduce_slabs": [_P, _L, _I, _P, _L, _I, _P],
     "vtp_gemm_splits": [_I, _I],
     "vtp_gemm_tn_splits": [_I, _I, _I],
+    "vtp_gemm_qkv_rope": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],

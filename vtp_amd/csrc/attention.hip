@@ -139,11 +139,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_i, mx);
-      const float alpha = exp2f(m_i - m_new);
+      const float alpha = fast_exp2(m_i - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = exp2f(s[r] - m_new);
+        s[r] = fast_exp2(s[r] - m_new);
         rs += s[r];
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float pr = exp2f(s[r] * sc2 - lse2);
+        float pr = fast_exp2(s[r] * sc2 - lse2);
         if (key >= p.N || (CAUSAL && key > qi)) pr = 0.f;
         s[r] = pr * (dp[r] - dlt) * p.scale;
       }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const int qn = qs0 + 8 * g + 4 * hi + e;
-          float pv = exp2f(s[r] * sc2 - l4[e]);
+          float pv = fast_exp2(s[r] * sc2 - l4[e]);
           if (qn >= p.N || ki >= p.N || (CAUSAL && ki > qn)) pv = 0.f;
           pr[r] = pv;
           s[r] = pv * (dp[r] - d4[e]) * p.scale;

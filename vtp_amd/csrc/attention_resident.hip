@@ -169,7 +169,7 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Ks, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = exp2f(s[r] * sc2 - m2);
+    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * sc2 - m2);
     if (kb == last) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vs, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = exp2f(s[r] * sc2 - lse2) * (dp[r] - dlt) * p.scale;
+    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * sc2 - lse2) * (dp[r] - dlt) * p.scale;
     if (kb == last) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        float pv = exp2f(s[r] * sc2 - l4[e]);
+        float pv = fast_exp2(s[r] * sc2 - l4[e]);
         if (qblk == last && qblk * 32 + 8 * g + 4 * hi + e >= p.N) pv = 0.f;
         pr[r] = pv;
         s[r] = pv * (dp[r] - d4[e]) * p.scale;

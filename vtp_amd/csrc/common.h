@@ -58,6 +58,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// 2^x as ONE v_exp_f32 (exp2f() adds a denormal-range fix-up: 6 VALU instead of 1); results below 2^-126 flush to 0, which is
+// what a softmax numerator wants
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

@@ -542,6 +542,26 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   return VTP_OK;
 }
 
+// qkv projection + apply_rope in one launch (attention.py:115 + :70-89): C bf16 [M, N] = A W^T + bias, then the q and k thirds
+// (columns < rope_cols) of every row m with rope_pos[m] >= 0 are rotated with row rope_pos[m] of the bf16 sin / cos tables.
+extern "C" int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* C, int ldc, int M, int N,
+                                 int K, const int* rope_pos, const void* rope_sin, const void* rope_cos, int rope_cols,
+                                 void* stream) {
+  VTP_REQUIRE(A && W && C && rope_pos && rope_sin && rope_cos, "vtp_gemm_qkv_rope: null operand");
+  VTP_REQUIRE(M > 0 && N > 0 && K > 0, "vtp_gemm_qkv_rope: bad shape M=%d N=%d K=%d", M, N, K);
+  VTP_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && ldc % 8 == 0, "vtp_gemm_qkv_rope: K, N, lda, ldb, ldc must be multiples of 8");
+  VTP_REQUIRE(rope_cols % 128 == 0 && rope_cols <= N, "vtp_gemm_qkv_rope: rope_cols must be a multiple of 128 (head_dim 64, two heads per 128-column wave tile)");
+  VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)rope_sin % 16 == 0) &&
+              ((uintptr_t)rope_cos % 16 == 0), "vtp_gemm_qkv_rope: operands must be 16-B aligned");
+  GemmArgs a{};
+  a.A = (const bf16*)A; a.B = (const bf16*)W; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = 1.f;
+  a.xcd_swizzle = swz_flags() | 2;  // the rotation lives in the LDS-staged store path
+  a.k_split = (K + 63) / 64 * 64;
+  a.rope_pos = rope_pos; a.rope_sin = (const bf16*)rope_sin; a.rope_cos = (const bf16*)rope_cos; a.rope_cols = rope_cols;
+  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg(M, N, K, VTP_EPI_BF16, 1), (hipStream_t)stream);
+}
+
 // C[M,N] (f32) = A[K,M]^T * B[K,N]  (A, B bf16 row-major with the reduction dimension K = tokens as rows):
 // the weight-gradient GEMM dW = dY^T X straight from the activation layouts (no transposed copies).
 extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid,

@@ -28,6 +28,13 @@ struct GemmArgs {
   // 3x3 convolution as an implicit GEMM over a zero-bordered NHWC image stack (vtp_conv3x3): A = [NB*(H+2)*(W+2), conv_cin]
   // pixel rows, k-tile kt reads tap (kt*64)/conv_cin at row offset (ky-1)*conv_w2 + (kx-1).  conv_cin == 0: plain GEMM.
   int conv_cin, conv_w2, conv_p, conv_h2;
+  // fused apply_rope (attention.py:70-89) in the bf16 epilogue of the qkv projection: output row m is rotated with row
+  // rope_pos[m] of the bf16 tables [*, 64] (rope_pos[m] < 0: cls / prefix rows, not rotated); only columns < rope_cols (the
+  // q and k thirds; a multiple of 128) are rotated.  rope_pos == null: plain epilogue.
+  const int* rope_pos;
+  const bf16* rope_sin;
+  const bf16* rope_cos;
+  int rope_cols;
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
@@ -91,8 +98,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
 #pragma unroll
         for (int t = 0; t < 32 * CPR / 64; ++t) {
           const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
-          const bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+          bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
           const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+          if (p.rope_pos && n0 + wn * WTN < p.rope_cols) {  // wave-uniform: this wave's columns are q / k heads
+            // a head is 8 consecutive 16-B chunks of the row image: the partner element d +- 32 sits in chunk c ^ 4 = lane ^ 4.
+            // out = x*cos + rot_half(x)*sin with the three eager-bf16 roundings of the reference (rope_qk_kernel, bit-identical)
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const i32x4 vi = (i32x4)val;
+            i32x4 pi;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pi[w] = __shfl_xor(vi[w], 4, 64);
+            const bf16x8 prt = (bf16x8)pi;
+            const int pos = m < p.M ? p.rope_pos[m] : -1;
+            if (pos >= 0) {
+              const bf16x8 cs = *(const bf16x8*)(p.rope_cos + (size_t)pos * 64 + (c & 7) * 8);
+              const bf16x8 sn = *(const bf16x8*)(p.rope_sin + (size_t)pos * 64 + (c & 7) * 8);
+              const float sg = (c & 4) ? 1.f : -1.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                val[e] = f2bf(bf2f(f2bf(bf2f(val[e]) * bf2f(cs[e]))) + bf2f(f2bf(sg * bf2f(prt[e]) * bf2f(sn[e]))));
+            }
+          }
           if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
         }
       }

@@ -250,6 +250,7 @@ class Overlap:
 
 
 OVERLAP = Overlap()
+FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
 WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
 
@@ -378,6 +379,33 @@ class Stack:
             b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
             self.blocks.append(b)
 
+    def _rope_plan(self, ws: Workspace, segs, prefix_tokens: int, M: int):
+        """(rope_pos int32 [M], sin, cos) for the fused qkv + RoPE epilogue: rope_pos[m] = row of the concatenated per-segment
+        tables that rotates token row m, -1 for prefix (cls) rows.  Built once per workspace (static segment structure)."""
+        if self.style != "vit" or all(rp is None for _, _, rp in segs) or (2 * self.D) % 128:
+            return None
+        hit = getattr(ws, "_rope_plan", None)
+        key = tuple((b, n, None if rp is None else rp[0].data_ptr()) for b, n, rp in segs) + (prefix_tokens,)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pos, tabs_s, tabs_c, base = [], [], [], 0
+        for Bs, Ns, rp in segs:
+            if rp is None:
+                pos.append(torch.full((Bs * Ns,), -1, dtype=torch.int32))
+                continue
+            hw = rp[0].shape[0]
+            assert Ns - prefix_tokens == hw, (Ns, prefix_tokens, hw)
+            one = torch.cat([torch.full((prefix_tokens,), -1, dtype=torch.int32), torch.arange(hw, dtype=torch.int32) + base])
+            pos.append(one.repeat(Bs))
+            tabs_s.append(rp[0])
+            tabs_c.append(rp[1])
+            base += hw
+        dev = self.store.device
+        plan = (torch.cat(pos).to(dev), torch.cat(tabs_s).contiguous(), torch.cat(tabs_c).contiguous())
+        assert plan[0].numel() == M
+        ws._rope_plan = (key, plan)
+        return plan
+
     @staticmethod
     def _rows(segs):
         """(first row, B, N, rope) of every segment of a row-concatenated token buffer."""
@@ -397,6 +425,7 @@ class Stack:
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
         saved_all = []
+        rope_plan = self._rope_plan(ws, segs, prefix_tokens, M) if FUSE_ROPE else None
         for i, b in enumerate(self.blocks):
             t = f"{i}." if train else ""
             xn1 = ws.get(t + "xn1", (M, D), BF)
@@ -413,10 +442,13 @@ class Stack:
             x_in = x  # block input (previous block's xout buffer) is kept for norm1 backward
 
             ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
-            ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
+            if rope_plan is not None:  # apply_rope rides in the epilogue of the qkv projection (all segments, one launch)
+                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, M, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+            else:
+                ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
             for r0, Bs, Ns, rp in self._rows(segs):
                 q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
-                if rp is not None:
+                if rp is not None and rope_plan is None:
                     ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
                 ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o_s, lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D,
                              scale, self.causal)

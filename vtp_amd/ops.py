@@ -42,6 +42,12 @@ def gemm_nt(a, b, c, *, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, c2
     _lib.check(rc, "vtp_gemm_nt")
 
 
+def gemm_qkv_rope(a, w, bias, c, M, N, K, rope_pos, rope_sin, rope_cos, rope_cols):
+    """c bf16 [M, N] = a @ w^T + bias with apply_rope fused (rows with rope_pos >= 0, columns < rope_cols)."""
+    _lib.check(_lib_().vtp_gemm_qkv_rope(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(c), c.stride(0), M, N, K,
+                                         _p(rope_pos), _p(rope_sin), _p(rope_cos), rope_cols, _s()), "vtp_gemm_qkv_rope")
+
+
 def norm_fwd(x, w, b, y, stats, M, D, eps, kind):
     _lib.check(_lib_().vtp_norm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, D, eps, kind, _s()), "vtp_norm_fwd")
 
