@@ -51,10 +51,15 @@ int vtp_gemm_splits(int K, int splits);
 int vtp_gemm_tn_splits(int M, int N, int K);
 /* C[M,N] f32 = A[K,M]^T * B[K,N]: A, B bf16 row-major with the reduction dimension (tokens) as ROWS -- the weight-gradient
  * GEMM dW = dY^T X of every linear, read straight from the activation layouts (fragments are formed with the gfx950 LDS
- * transpose read; no transposed copies).  epilogue VTP_EPI_F32 (C = resid + acc, pass resid = C to accumulate) or
- * VTP_EPI_F32_SLAB (split-K slabs, see above).  a_/b_ remaps act on the token rows of A / B, c_ on the rows of C. */
+ * transpose read; no transposed copies).  epilogue VTP_EPI_F32 (C = resid + acc, pass resid = C to accumulate),
+ * a_colsum (optional, f32 [M], ACCUMULATED, rows mapped like C's): column sums of A over the tokens = the bias gradient of the
+ * same linear layer (nn.Linear backward: db = dY.sum(0)); fused into the GEMM where the tile configuration allows, else a
+ * column-sum pass on the same stream.
+ * VTP_EPI_F32_SLAB (split-K slabs, see above) or VTP_EPI_F32_ATOMIC (split-K slices add into C with fp32 atomics: no slab
+ * round trip through HBM; the summation order, hence the last bits, vary from run to run).  a_/b_ remaps act on the token rows of A / B, c_ on the rows of C. */
 int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid, int M, int N,
-                int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre, int splits, void* stream);
+                int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre, int splits,
+                float* a_colsum, void* stream);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);

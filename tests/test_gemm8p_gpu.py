@@ -142,3 +142,35 @@ def test_gemm8p_tn_swiglu_c_remap():
     ref = torch.zeros_like(ref_i)
     ref[dst] = ref_i
     check(C, ref, "gemm8p_tn swiglu c_remap", bf16_out=False, scale=2e-5)
+
+
+@pytest.mark.parametrize("Mo,No,K,splits,swiglu", [(768, 768, 8224, 9, False), (352, 128, 4100, 1, True), (4096, 768, 34144, 5, True),
+                                                   (2304, 768, 34144, 9, False)])
+def test_gemm8p_tn_fused_bias_gradient(Mo, No, K, splits, swiglu):
+    """a_colsum: db[m] += sum_t dy[t, m] inside the weight-gradient GEMM (accumulating, SwiGLU row map, split-K, K tail)."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(Mo + K)
+    A = bf(torch.randn(K, Mo, device=DEV, generator=g) + 0.25)
+    Bm = bf(torch.randn(K, No, device=DEV, generator=g))
+    H = Mo // 2
+    S = o.gemm_splits(K, splits)
+    db = torch.ones(Mo, device=DEV)
+    kw = dict(c_remap=(-1, H)) if swiglu else {}
+    if S == 1:
+        C = torch.zeros(Mo, No, device=DEV)
+        o.gemm_tn(A, Bm, C, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, resid=C, epi=o.EPI_F32, a_colsum=db, **kw)
+    else:
+        slab = torch.empty(S * Mo * No, device=DEV)
+        o.gemm_tn(A, Bm, slab, M=Mo, N=No, K=K, lda=Mo, ldb=No, ldc=No, ldc2=Mo * No // 4, epi=o.EPI_F32_SLAB, splits=S, a_colsum=db,
+                  **kw)
+        C = slab.view(S, Mo, No).sum(0)
+    ref_c = A.float().T @ Bm.float()
+    ref_b = A.float().sum(0)
+    if swiglu:
+        gi = torch.arange(Mo, device=DEV)
+        dst = (gi // 16) * 8 + (gi % 8) + ((gi % 16) >= 8) * H
+        rc, rb = torch.zeros_like(ref_c), torch.zeros_like(ref_b)
+        rc[dst], rb[dst] = ref_c, ref_b
+        ref_c, ref_b = rc, rb
+    check(C, ref_c, f"gemm8p_tn + colsum C {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)
+    check(db, 1 + ref_b, f"gemm8p_tn fused bias gradient {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)

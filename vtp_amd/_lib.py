@@ -35,7 +35,7 @@ SIGNATURES = {
     "vtp_gemm_splits": [_I, _I],
     "vtp_gemm_tn_splits": [_I, _I, _I],
     "vtp_gemm_qkv_rope": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
-    "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],

@@ -564,15 +564,19 @@ extern "C" int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb,
 
 // C[M,N] (f32) = A[K,M]^T * B[K,N]  (A, B bf16 row-major with the reduction dimension K = tokens as rows):
 // the weight-gradient GEMM dW = dY^T X straight from the activation layouts (no transposed copies).
+extern "C" int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_swiglu_h, int in_grp, int in_pre, int R, int C,
+                               void* stream);
+
 extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid,
                            int M, int N, int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre,
-                           int splits, void* stream) {
+                           int splits, float* a_colsum, void* stream) {
   VTP_REQUIRE(A && B && C, "vtp_gemm_tn: null operand");
   VTP_REQUIRE(M > 0 && N > 0 && K > 0, "vtp_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
   VTP_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "vtp_gemm_tn: M, N, lda, ldb must be multiples of 8");
   VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "vtp_gemm_tn: operands must be 16-B aligned");
-  VTP_REQUIRE(epilogue == VTP_EPI_F32 || epilogue == VTP_EPI_F32_SLAB, "vtp_gemm_tn: epilogue must be F32 (accumulate via resid) or F32_SLAB");
-  VTP_REQUIRE(splits >= 1 && (splits == 1 || epilogue == VTP_EPI_F32_SLAB), "vtp_gemm_tn: split-K needs the slab epilogue");
+  VTP_REQUIRE(epilogue == VTP_EPI_F32 || epilogue == VTP_EPI_F32_SLAB || epilogue == VTP_EPI_F32_ATOMIC,
+              "vtp_gemm_tn: epilogue must be F32 (accumulate via resid), F32_SLAB or F32_ATOMIC");
+  VTP_REQUIRE(splits >= 1 && (splits == 1 || epilogue != VTP_EPI_F32), "vtp_gemm_tn: split-K needs the slab or the atomic epilogue");
   VTP_REQUIRE(epilogue != VTP_EPI_F32_SLAB || ldc2 > 0, "vtp_gemm_tn: slab epilogue needs ldc2 = slab stride / 4");
   GemmArgs a{};
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C; a.C2 = nullptr; a.bias = nullptr; a.gamma = nullptr; a.resid = resid;
@@ -586,6 +590,16 @@ extern "C" int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void*
   int cfg = g_force_cfg >= 0 ? g_force_cfg : (use_8p_tn(M, N, K, splits, a) ? 8 : 5);
   if (cfg != 2 && cfg != 3 && cfg != 5 && cfg != 8 && cfg != 16 && cfg != 21) cfg = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (a_colsum) {  // bias gradient db[m] += sum_t A[t, m]: fused into the 8-phase kernel, a separate pass otherwise
+    VTP_REQUIRE(c_grp <= 0, "vtp_gemm_tn: a_colsum supports the identity and the SwiGLU (c_grp = -1) row maps only");
+    if (cfg == 8 && a_grp == 0 && b_grp == 0 && gemm8p_fits(a, true)) {
+      a.colsum = a_colsum;
+    } else {
+      const int rc = vtp_colsum_bf16(A, lda, a_colsum, c_grp < 0 ? c_pre : 0, a_grp, a_pre, K, M, stream);
+      if (rc != VTP_OK) return rc;
+    }
+  }
   if (epilogue == VTP_EPI_F32) return launch_gemm<EPI_F32, true>(a, 1, cfg, s);
+  if (epilogue == VTP_EPI_F32_ATOMIC) return launch_gemm<EPI_F32_ATOMIC, true>(a, splits, cfg, s);
   return launch_gemm<EPI_F32_SLAB, true>(a, splits, cfg, s);
 }

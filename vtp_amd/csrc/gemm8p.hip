@@ -217,6 +217,23 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       }
   };
 
+  // TN: column sums of A (bias gradient) ride along -- the wc == 0 waves of the first tile column add up the A fragments they
+  // load anyway (v_dot2_f32_bf16 against ones: 4 VALU per fragment, in the shadow of the MFMAs), one atomic per row per tile
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  bool do_csum = false;
+  auto add_csum = [&](const bf16x8 (&f)[2][4], int jbase) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const bf16x2_t v = {f[jj][ks][2 * w], f[jj][ks][2 * w + 1]};
+          csum[jbase + jj] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, csum[jbase + jj], false);
+        }
+  };
   f32x16 acc[2][4];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -275,6 +292,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
     tile_origin(ti, m0, n0);
+    if constexpr (TRANS) do_csum = p.colsum != nullptr && wc == 0 && n0 == 0;
     if (STAGGER && wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
@@ -291,6 +309,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
       seg_barrier();
       mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1], I3{});
+      if constexpr (TRANS) {
+        if (do_csum) add_csum(a1, 0);
+      }
       seg_barrier();
       // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63)
       load_b(kb + 2 * P8_SLOT, b2);
@@ -305,6 +326,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       if (!DMA_IN_MMA && s_h < H) issue(I1{});
       seg_barrier();
       mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1], I1{});
+      if constexpr (TRANS) {
+        if (do_csum) add_csum(a2, 2);
+      }
       seg_barrier();
       // ---- phase 3: quadrant (cols 0..31, rows 64..127); the next k-tile's four half-tiles must have landed
       if (!DMA_IN_MMA && s_h < H) issue(I2{});
@@ -314,6 +338,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       seg_barrier();
     }
     if (STAGGER && wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
+    if constexpr (TRANS) {
+      if (do_csum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = csum[j] + __shfl_xor(csum[j], 32, 64);  // the two k halves of the fragment layout
+          const int m = m0 + wr * 128 + j * 32 + (lane & 31);
+          if (hi == 0 && m < p.M) unsafeAtomicAdd(p.colsum + remap_row(m, p.c_grp, p.c_pre), v);
+          csum[j] = 0.f;
+        }
+      }
+    }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
     gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane);
     zero_acc();
@@ -376,6 +411,7 @@ int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   if (epi == EPI_F32) return launch8p<EPI_F32, true>(a, 1, s);
+  if (epi == EPI_F32_ATOMIC) return launch8p<EPI_F32_ATOMIC, true>(a, splits, s);
   static const int var = getenv("VTP_GEMM8P_VAR") ? atoi(getenv("VTP_GEMM8P_VAR")) : 0;
   if (var == 4) return launch8p<EPI_F32_SLAB, true, 4>(a, splits, s);
   return launch8p<EPI_F32_SLAB, true>(a, splits, s);

@@ -35,6 +35,9 @@ struct GemmArgs {
   const bf16* rope_sin;
   const bf16* rope_cos;
   int rope_cols;
+  // TRANS (weight-gradient) mode: if non-null, the column sums of A over the reduction rows (= the bias gradient of the linear
+  // layer, db[m] = sum_t dy[t, m]) are ACCUMULATED into colsum[remap_row(m, c_grp, c_pre)] by the kernels that support it
+  float* colsum;
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .ops import EPI_BF16, EPI_F32, EPI_F32_SLAB, EPI_GELU, EPI_SWIGLU, pad8
+from .ops import EPI_BF16, EPI_F32, EPI_F32_ATOMIC, EPI_F32_SLAB, EPI_GELU, EPI_SWIGLU, pad8
 
 
 # =====================================================================================================================
@@ -253,6 +253,9 @@ OVERLAP = Overlap()
 FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
 WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
+# split-K weight gradients: private fp32 slabs + one reduce launch (default; bit-reproducible summation order) or fp32 atomics
+# straight into the flat gradient (VTP_WGRAD_ATOMIC=1)
+WGRAD_ATOMIC = _env_flag("VTP_WGRAD_ATOMIC", "0")  # measured: fp32 atomics from the MFMA epilogue halve the step rate
 
 
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
@@ -286,13 +289,14 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
     def wgrad():
         if WGRAD_TN:
             # dW[N,K] = dy[M,N]^T x[M,K] straight from the activation layouts (LDS transpose reads inside the GEMM)
-            if gb is not None:
-                ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
+            # db = colsum(dy) rides in the wgrad GEMM (fused in the 8-phase kernel, else a column-sum pass inside vtp_gemm_tn)
             kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap,
-                      c_remap=c_remap)
+                      c_remap=c_remap, a_colsum=gb)
             St = ops.gemm_tn_splits(N, K, M)  # tile-configuration aware (8-phase 256x256 kernel: tiles x splits = 256 CUs)
             if St == 1:
                 ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)
+            elif WGRAD_ATOMIC:  # slices add straight into the flat gradient: no slab write + read + reduce launch
+                ops.gemm_tn(dy_b, x_b, gw, epi=EPI_F32_ATOMIC, splits=St, **kw)
             else:
                 n_el = N * K
                 slab = ws.get("T.slab", (St * n_el,), F32)

@@ -134,10 +134,11 @@ def adamw_dev(p, g, m, v, p_bf16, n, hyper):
 
 
 def gemm_tn(a, b, c, *, M, N, K, lda, ldb, ldc, ldc2=0, resid=None, epi=EPI_F32, a_remap=(0, 0), b_remap=(0, 0),
-            c_remap=(0, 0), splits=1):
-    """c[M,N] f32 = a[K,M]^T @ b[K,N]  (a, b bf16 row-major, K = token rows)."""
+            c_remap=(0, 0), splits=1, a_colsum=None):
+    """c[M,N] f32 = a[K,M]^T @ b[K,N]  (a, b bf16 row-major, K = token rows).  a_colsum (f32 [M], accumulated): column sums
+    of a over the tokens (the bias gradient of the same linear layer)."""
     rc = _lib_().vtp_gemm_tn(_p(a), lda, _p(b), ldb, _p(c), ldc, ldc2, _p(resid), M, N, K, epi, a_remap[0], a_remap[1],
-                             b_remap[0], b_remap[1], c_remap[0], c_remap[1], splits, _s())
+                             b_remap[0], b_remap[1], c_remap[0], c_remap[1], splits, _p(a_colsum), _s())
     _lib.check(rc, "vtp_gemm_tn")
 
 
