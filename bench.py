@@ -11,6 +11,12 @@ One "step" = one full optimizer step of the hot path on one batch of synthetic 2
 --perceptual-weight), contrastive (InfoNCE with feature all-gather) and self-supervised (DINO + iBOT, EMA teacher);
 config.workload says exactly what ran.  Rank 0 prints ONE JSON line.
 
+Inside the timed region, EVERY step draws fresh block-wise iBOT masks (vtp_amd.data.collate_ssl_masks, host numpy), builds
+the SSL index plan (VTPTrainer.prepare_ssl) and copies it to the device: the captured hipGraph is keyed by the padded
+masked-token buffer size (the collate's `upperbound`, vtp.py:432-439) and serves every draw.  The image / caption / crop
+tensors stay resident in HBM (the contract's "inputs already resident").  `lpips_on` repeats the measurement (fewer steps) with
+the perceptual term of north_star switched on.
+
 Also reported on the same line:
   roofline     -- the dominant kernel (gemm_nt bf16 MFMA GEMM): algorithmic FLOPs (2*M*N*K per launch) / average launch
                   duration measured with HIP events on the launch stream over one instrumented step run right after
@@ -57,20 +63,27 @@ def synthetic_captions(B, T, vocab, device, seed):
     return ids.to(device)
 
 
-def synthetic_ssl(B, res, device, seed, local_res=96, n_local=8):
-    """2 global crops at res^2 + 8 local crops at 96^2 per image (DINOv2 convention, unpinned); iBOT masks:
-    half of the global crops masked at a ratio ~ U(0.1, 0.5)."""
+def synthetic_crops(B, res, device, seed, local_res=96, n_local=8):
+    """2 global crops at res^2 + 8 local crops at 96^2 per image (DINOv2 convention, unpinned)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    hw = (res // 16) ** 2
     gc = torch.randn(2 * B, 3, res, res, device=device, generator=g)
     lc = torch.randn(n_local * B, 3, local_res, local_res, device=device, generator=g)
-    gh = torch.Generator().manual_seed(seed)
-    masks = torch.zeros(2 * B, hw, dtype=torch.bool)
-    for i in range(2 * B):
-        if torch.rand(1, generator=gh).item() < 0.5:
-            ratio = 0.1 + 0.4 * torch.rand(1, generator=gh).item()
-            masks[i, torch.randperm(hw, generator=gh)[:int(ratio * hw)]] = True
-    return gc, lc, masks
+    return gc, lc
+
+
+class MaskStream:
+    """Fresh iBOT masks per step: half of the global crops masked block-wise at ratios stratified over (0.1, 0.5) (the
+    DINOv2 collate, vtp_amd/data.py); `upperbound` is the same for every draw, so one captured graph serves them all."""
+
+    def __init__(self, B, res, seed):
+        import numpy as np
+        from vtp_amd.data import collate_ssl_masks
+        self.rng = np.random.default_rng(seed)
+        self.n, self.grid, self.collate = 2 * B, (res // 16, res // 16), collate_ssl_masks
+
+    def draw(self):
+        d = self.collate(self.n, self.grid, 0.5, (0.1, 0.5), self.rng)
+        return d["masks"], d["upperbound"]
 
 
 def text_fwd_gflop(D, L, T):
@@ -87,42 +100,76 @@ def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
     return f / 1e9
 
 
-def cpu_baseline(model, B_cpu, res, clip, budget_s=20.0):
-    """The CPU oracle timed on the host: same train step (fwd + losses + autograd bwd + AdamW), fp32, all cores."""
+def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=14.0):
+    """The CPU oracle (kind "port": oracle/vtp_oracle.py is a PyTorch restatement of the reference, itself PyTorch) timed on
+    the host cores on a bounded sample of the SAME workload: one full train step (fwd + every loss that ran on the GPU + autograd
+    bwd + AdamW) at a scaled-down batch, fp32 and under torch.autocast("cpu", bf16).  2 warm-up steps, then
+    up to 10 timed steps or `budget_s` seconds per precision, median step time."""
     from oracle import vtp_oracle as O
+    import numpy as np
+    from vtp_amd.data import collate_ssl_masks
     cfg = model.config
     sd = {k: v.detach().float().cpu().clone() if v.dtype == torch.float32 else v.detach().cpu().clone()
           for k, v in model.state_dict().items()}
-    keys = [k for k in sd if sd[k].dtype == torch.float32 and (clip or k.startswith("trunk.") or k.startswith("pixel_decoder."))]
+    train_pref = ("trunk.", "pixel_decoder.") + (("visual_proj.", "text_transformer.", "token_embedding.", "positional_embedding",
+                                                   "ln_final.", "text_projection", "logit_scale") if clip else ()) \
+        + (("dino_head.",) if do_ssl else ())
+    keys = [k for k in sd if sd[k].dtype == torch.float32 and k.startswith(train_pref)]
     for k in keys:
         sd[k].requires_grad_(True)
     opt = torch.optim.AdamW([sd[k] for k in keys], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-    img = torch.randn(B_cpu, 3, res, res, generator=torch.Generator().manual_seed(99))
+    g = torch.Generator().manual_seed(99)
+    img = torch.randn(B_cpu, 3, res, res, generator=g)
     txt = synthetic_captions(B_cpu, cfg.text_context_length, cfg.text_vocab_size, "cpu", 98)
+    hv, hd, ht = cfg.vision_num_heads, cfg.decoder_num_heads, cfg.text_num_heads
+    if do_ssl:
+        gc = torch.randn(2 * B_cpu, 3, res, res, generator=g)
+        lc = torch.randn(8 * B_cpu, 3, 96, 96, generator=g)
+        masks = collate_ssl_masks(2 * B_cpu, (res // 16, res // 16), 0.5, (0.1, 0.5), np.random.default_rng(97))["masks"]
+        K = sd["dino_head.last_layer.weight_v"].shape[0]
+        c_d, c_i = torch.zeros(K), torch.zeros(K)
     n_thr = torch.get_num_threads()
 
     def step():
         opt.zero_grad(set_to_none=True)
         if clip:
-            l1, lc = O.rec_clip_train_loss(sd, img, txt, cfg.vision_num_heads, cfg.decoder_num_heads, cfg.text_num_heads)
-            loss = l1 + lc
+            l1, lc_ = O.rec_clip_train_loss(sd, img, txt, hv, hd, ht)
+            loss = l1 + lc_
         else:
-            loss = O.rec_train_loss(sd, img, cfg.vision_num_heads, cfg.decoder_num_heads)
+            loss = O.rec_train_loss(sd, img, hv, hd)
+        if do_ssl:
+            t_out, s_out = O.ssl_outputs(sd, gc, lc, masks, hv)
+            loss = loss + O.ssl_loss(t_out, s_out, masks, c_d, c_i, 8)
         loss.backward()
         opt.step()
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        step()
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 10:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(n * B_cpu / dt, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(),
-            "kind": "port", "sample": f"{n} fp32 train steps (fwd + {'L1+CLIP' if clip else 'L1'} loss + bwd + AdamW) of the same model "
-                                      f"at batch {B_cpu} after 1 warm-up"}
+    def timed(autocast):
+        import contextlib
+        ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+        ts = []
+        t_all = time.perf_counter()
+        for i in range(12):
+            t0 = time.perf_counter()
+            with ctx():
+                step()
+            dt = time.perf_counter() - t0
+            if i >= n_warm:
+                ts.append(dt)
+            if time.perf_counter() - t_all > budget_s and len(ts) >= 2:
+                break
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    n_warm = 1 if do_ssl else 2  # the full step takes ~15 s on the host: 1 warm-up + >= 2 timed steps per precision
+    t32, n32 = timed(False)
+    t16, n16 = timed(True)
+    objs = "L1" + ("+CLIP" if clip else "") + ("+DINO/iBOT (K=%d prototypes, 2 global + 8 local crops/img, EMA-teacher fwd)" % K if do_ssl else "")
+    return {"value": round(B_cpu / t32, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"median of {n32} fp32 train steps (fwd + {objs} loss + bwd + AdamW) of the same model at batch {B_cpu} "
+                      f"after {n_warm} warm-up step(s)",
+            "bf16_autocast": {"value": round(B_cpu / t16, 3), "unit": "images/sec", "steps": n16,
+                              "note": 'same step under torch.autocast("cpu", dtype=torch.bfloat16)'},
+            "ms_per_step_fp32": round(t32 * 1e3, 1), "threads": n_thr}
 
 
 def main():
@@ -133,7 +180,8 @@ def main():
     ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-lpips-run", action="store_true", help="skip the second measurement with the perceptual term on")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
     ap.add_argument("--prototypes", type=int, default=65536, help="DINO head out_dim K (DINOv2 default 65536; unpinned)")
     ap.add_argument("--perceptual-weight", type=float, default=0.0,
@@ -168,59 +216,79 @@ def main():
     B = args.batch or B
     img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
 
-    def build_trainer(use_graphs: bool):
+    crops = synthetic_crops(B, res, dev, 777 + rank) if do_ssl else None
+    mask_stream = MaskStream(B, res, 555 + rank) if do_ssl else None
+    state = {"n_masked": [], "Ts": set()}
+
+    def build_trainer(use_graphs: bool, perceptual_weight: float):
         torch.manual_seed(0)
         model = (VTP(VTPConfig(**cfg_kw), dino_out_dim=args.prototypes) if do_ssl else VTPModel(VTPConfig(**cfg_kw))).to(dev)
         lp = None
-        if args.perceptual_weight > 0:
+        if perceptual_weight > 0:
             from vtp_amd import LPIPS
             lp = LPIPS().reset_parameters(0).to(dev)
         trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=use_graphs, lpips=lp,
-                             perceptual_weight=args.perceptual_weight)
+                             perceptual_weight=perceptual_weight)
         txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
+        return model, lp, trainer, txt
+
+    def one_step(trainer, txt):
+        """the step as a training loop runs it: fresh masks -> index plan -> H2D -> optimizer step"""
         ssl = None
         if do_ssl:
-            gc, lc, masks = synthetic_ssl(B, res, dev, 777 + rank)
-            ssl = trainer.prepare_ssl(gc, lc, masks)
-        return model, lp, trainer, txt, ssl
+            masks, upper = mask_stream.draw()
+            ssl = trainer.prepare_ssl(crops[0], crops[1], masks, upperbound=upper)
+            state["n_masked"].append(ssl["plan"]["n_masked"])
+            state["Ts"].add(ssl["plan"]["Ts"])
+            state["last_plan"] = ssl["plan"]
+        return trainer.step(img, txt, ssl)
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    launch = "eager" if args.no_graphs else "hipGraph segments"
-    model, lp, trainer, txt, ssl = build_trainer(not args.no_graphs)
-    try:
-        for _ in range(args.warmup):
-            trainer.step(img, txt, ssl)
+    def measure(perceptual_weight: float, steps: int, warmup: int):
+        launch = "eager" if args.no_graphs else "hipGraph segments"
+        model, lp, trainer, txt = build_trainer(not args.no_graphs, perceptual_weight)
+        try:
+            for _ in range(warmup):
+                one_step(trainer, txt)
+            sync()
+        except RuntimeError as e:  # a capture problem must not cost the measurement: same step, eager launches
+            if args.no_graphs:
+                raise
+            print(f"[bench] hipGraph path failed ({str(e)[:200]}); falling back to eager launches", file=sys.stderr, flush=True)
+            launch = "eager (hipGraph capture failed on this configuration)"
+            model, lp, trainer, txt = build_trainer(False, perceptual_weight)
+            for _ in range(warmup):
+                one_step(trainer, txt)
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, closs = one_step(trainer, txt)
         sync()
-    except RuntimeError as e:  # a capture problem must not cost the measurement: same step, eager launches
-        if args.no_graphs:
-            raise
-        print(f"[bench] hipGraph path failed ({str(e)[:200]}); falling back to eager launches", file=sys.stderr, flush=True)
-        launch = "eager (hipGraph capture failed on this configuration)"
-        model, lp, trainer, txt, ssl = build_trainer(False)
-        for _ in range(args.warmup):
-            trainer.step(img, txt, ssl)
-        sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, closs = trainer.step(img, txt, ssl)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t)
+        return model, lp, trainer, txt, launch, elapsed, loss, closs
+
+    model, lp, trainer, txt, launch, elapsed, loss, closs = measure(args.perceptual_weight, args.steps, args.warmup)
+    ssl = None
+    if do_ssl:  # the instrumented step below reuses the last drawn batch
+        masks, upper = mask_stream.draw()
+        ssl = trainer.prepare_ssl(crops[0], crops[1], masks, upperbound=upper)
     loss_val, closs_val = float(loss), float(closs)
+    ssl_loss_val = float(trainer.ssl_loss_sum) if do_ssl else 0.0
 
     # ---- dominant-kernel roofline: one instrumented step, HIP events (recorded on the launch stream) around every launch of
     # the MFMA GEMM family -- gemm_nt (forward / dgrad) and gemm_tn (wgrad) are the same kernel template (rank 0)
     roof = None
     recs = []
     import vtp_amd.engine as eng
-    orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn
+    orig_nt, orig_tn, orig_qkv = ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope
 
     def timed(fn):
         def run(a, b, c, **kw):
@@ -234,8 +302,15 @@ def main():
             recs.append((2.0 * M * N * K, e0, e1))
         return run
 
+    def timed_qkv(a, w, bias, c, M, N, K, *rest):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_qkv(a, w, bias, c, M, N, K, *rest)
+        e1.record()
+        recs.append((2.0 * M * N * K, e0, e1))
+
     if rank == 0:
-        ops.gemm_nt, ops.gemm_tn = timed(orig_nt), timed(orig_tn)
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope = timed(orig_nt), timed(orig_tn), timed_qkv
     trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
     overlap_was = eng.OVERLAP.enabled
     eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
@@ -243,26 +318,28 @@ def main():
         trainer.step(img, txt, ssl)  # every rank takes the step (it contains the collectives); rank 0 times its GEMMs
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_tn = orig_nt, orig_tn
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope = orig_nt, orig_tn, orig_qkv
         eng.OVERLAP.enabled = overlap_was
     if rank == 0:
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and args.workload == "vtp_base_full" and not args.batch:
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (2, 1)) if os.path.exists(q)), "")
+        if pmc and args.workload == "vtp_base_full" and not args.batch:
             try:  # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes of this command
                 d = json.load(open(pmc))
                 by, n = 0.0, 0
-                for fam in ("gemm_nt", "gemm_tn"):
+                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn"):
+                    if fam not in d:
+                        continue
                     # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2, MI355X_MICROARCH.md HBM)
                     by += 1024.0 * (2.0 * d[fam]["FETCH_SIZE"]["sum"] + d[fam]["WRITE_SIZE"]["sum"])
                     n += d[fam]["FETCH_SIZE"]["dispatches"]
-                traffic, traffic_src = round(by / n), "profiles/r01_pmc_summary.json (separate --pmc passes; bytes per launch)"
+                traffic, traffic_src = round(by / n), f"profiles/{os.path.basename(pmc)} (separate --pmc passes; bytes per launch)"
             except (KeyError, ValueError):
                 pass
-        roof = {"bound": "mfma", "kernel": "vtp::gemm_nt_kernel<...> (bf16 MFMA 32x32x16; NT fwd/dgrad + TN wgrad, all tile configs and epilogues)",
+        roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad + TN wgrad, 256x256 8-phase and ring tile configs, all epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
                 "avg_launch_us": round(ms * 1e3 / len(recs), 2), "gemm_ms_per_step": round(ms, 3),
@@ -291,8 +368,11 @@ def main():
         head = (3.0 * pl["Ts"] + (2 * B + pl["Tm"])) * tok_flop / 1e9 / B   # student fwd+bwd + teacher fwd, per image
         gflop_img += ssl_trunk + head
         gflop_ref += ssl_trunk + head
-        ssl_info = {"prototypes": dh["K"], "masked_tokens": pl["n_masked"], "student_head_rows": pl["Ts"],
-                    "global_crops": 2, "local_crops": 8, "local_res": 96, "ssl_loss": round(float(trainer.ssl_loss_sum), 4)}
+        nm = state["n_masked"]
+        ssl_info = {"prototypes": dh["K"], "masks": "fresh block-wise iBOT masks every step (host collate + index plan + H2D inside the timed region)",
+                    "masked_tokens_min_mean_max": [min(nm), round(sum(nm) / len(nm), 1), max(nm)], "masked_token_buffer_rows": pl["Tm"],
+                    "graph_keys_seen": len(state["Ts"]), "student_head_rows": pl["Ts"],
+                    "global_crops": 2, "local_crops": 8, "local_res": 96, "ssl_loss": round(ssl_loss_val, 4)}
     lpips_info = None
     if lp is not None:  # two VGG forwards (decoded + target) and one input-gradient pass
         lp_g = 3.0 * lp.forward_gflop(res, res)
@@ -301,6 +381,20 @@ def main():
         lpips_info = {"weight": args.perceptual_weight, "train_gflop_per_image": round(lp_g, 1),
                       "mean_lpips": round(float(trainer.lpips_val.mean()), 5), "weights": "seeded random (vgg.pth unavailable offline)"}
     ips = world * B * args.steps / elapsed
+    lpips_on = None
+    if args.perceptual_weight == 0 and not args.no_lpips_run and args.workload.startswith("vtp_base"):
+        # the same step with the perceptual (LPIPS / VGG16) term of north_star switched on: fewer steps, same protocol
+        del trainer, model
+        torch.cuda.empty_cache()
+        st2, wu2 = max(4, args.steps // 2), max(2, args.warmup // 2)
+        m2, lp2, tr2, _, launch2, el2, _, _ = measure(1.0, st2, wu2)
+        lp_g = 3.0 * lp2.forward_gflop(res, res)
+        ips2 = world * B * st2 / el2
+        lpips_on = {"value": round(ips2, 2), "unit": "images/sec", "ms_per_step": round(el2 / st2 * 1e3, 3), "steps": st2, "warmup": wu2,
+                    "perceptual_weight": 1.0, "launch": launch2, "train_gflop_per_image": round(gflop_img + lp_g, 1),
+                    "step_frac": round(ips2 / world * (gflop_img + lp_g) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                    "mean_lpips": round(float(tr2.lpips_val.mean()), 5), "weights": "seeded random VGG16 (vgg.pth is a download)"}
+        model = m2
     out = {
         "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload.startswith("vtp_base")
         else "images/sec/node VTP-S f16d64 256x256 train step",
@@ -317,16 +411,14 @@ def main():
                    "launch": launch, "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}" + ("" if backend == "nccl" else f" ({backend} rehearsal, shared GPU)"),
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
-        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info,
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info, "lpips_on": lpips_on,
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
     if rank == 0:
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res, clip)
-            if do_ssl:
-                out["cpu_baseline"]["note"] = "CPU sample covers the rec+clip objectives only (K=65536-prototype SSL on CPU exceeds the time bound)"
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res, clip, do_ssl)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

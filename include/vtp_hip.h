@@ -125,6 +125,10 @@ int vtp_transpose_bf16(const void* in, int ld_in, void* out, int ld_out, float* 
                        int in_pre, int R, int C, void* stream);
 /* out[c'] += sum_r in[r, c] for a bf16 [R, C] matrix (bias gradient); same column / row remaps as vtp_transpose_bf16. */
 int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_swiglu_h, int in_grp, int in_pre, int R, int C, void* stream);
+/* the same with the row count in DEVICE memory (rows >= n_rows_dev[0] are skipped; R_max sizes the launch): the masked-token
+ * count of an iBOT batch changes every step while the padded token buffers (vtp.py:432-439 `upperbound`) and a captured
+ * hipGraph do not */
+int vtp_colsum_bf16_rows(const void* in, int ld, float* out, const int* n_rows_dev, int R_max, int C, void* stream);
 /* backward of vtp_assemble_tokens' mask substitution: for masked patch rows d_mask_token += dx[row] and dx_bf16[row] = 0
  * (so the patch-embed wgrad / bias-grad skip them).  dx f32 / dx_bf16 [B*N, D], masks uint8 [B, N-1]. */
 int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N, int D,

@@ -1,8 +1,9 @@
 #!/bin/bash
-# same-box A/B of an environment switch:  bash scripts/gpu_ab.sh VAR on off
+# same-box A/B of the step rate: scripts/gpu_ab.sh "ENV1=a ENV2=b" "ENV1=c" ...   (each argument = one configuration's env)
 export PYTHONDONTWRITEBYTECODE=1
-VAR=${1:-VTP_TEXT_STREAM}; ON=${2:-1}; OFF=${3:-0}
 for rep in 1 2; do
-for v in $ON $OFF; do
-  echo "$VAR=$v: full $(env $VAR=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c72-90)  rec $(env $VAR=$v python bench.py --steps 12 --warmup 3 --no-cpu-baseline --workload vtp_base_rec 2>/dev/null | tail -1 | cut -c72-90)"
-done; done
+  for cfg in "$@"; do
+    v=$(env $cfg timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-lpips-run 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['gemm_ms_per_step'])")
+    echo "[$cfg] $v"
+  done
+done

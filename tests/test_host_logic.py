@@ -167,3 +167,38 @@ def test_lpips_module_has_the_reference_state_dict_layout_and_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
     assert set(LPIPS(use_dropout=False).state_dict().keys()) == {k.replace(".model.1.", ".model.0.") for k in sd}
+
+
+def test_block_mask_generator_and_ssl_collate():
+    """vtp_amd.data: block-wise iBOT masks + the collate that yields the reference's ssl_dict keys (vtp.py:365-374)."""
+    import numpy as np
+    import torch
+    from vtp_amd.data import BlockMaskGenerator, collate_ssl_batch, collate_ssl_masks
+    rng = np.random.default_rng(0)
+    gen = BlockMaskGenerator((16, 16), max_num_patches=128, rng=rng)
+    for n in (0, 5, 40, 128):
+        m = gen(n)
+        assert m.shape == (16, 16) and m.dtype == bool and int(m.sum()) <= n
+        if n >= 40:
+            assert int(m.sum()) >= n // 2  # blocks are added until the budget is (nearly) used
+    tot = []
+    for _ in range(20):
+        d = collate_ssl_masks(64, (16, 16), 0.5, (0.1, 0.5), rng)
+        masks = d["masks"]
+        assert masks.shape == (64, 256) and int((masks.sum(1) > 0).sum()) <= 32
+        nm = int(d["n_masked_patches"])
+        assert nm == int(masks.sum()) == d["mask_indices_list"].numel() <= d["upperbound"]
+        assert torch.equal(d["mask_indices_list"], masks.flatten().nonzero().flatten())
+        per = masks.sum(1).clamp(min=1).float()
+        assert torch.allclose(d["masks_weight"], (1.0 / per)[d["mask_indices_list"] // 256])
+        tot.append(nm)
+    assert len({collate_ssl_masks(64, (16, 16), 0.5, (0.1, 0.5), rng)["upperbound"] for _ in range(5)}) == 1  # fixed buffer size
+    assert 0.2 * 64 * 256 * 0.5 < sum(tot) / len(tot) < 0.4 * 64 * 256 * 0.5 * 1.2
+    B = 3
+    out = collate_ssl_batch([torch.randn(B, 3, 64, 64) for _ in range(2)], [torch.randn(B, 3, 32, 32) for _ in range(4)], rng=rng)
+    assert set(out) >= {"global_crops", "n_global_crops", "mask_indices_list", "n_masked_patches", "upperbound", "local_crops", "masks"}
+    assert out["global_crops"].shape == (2 * B, 3, 64, 64) and out["local_crops"].shape == (4 * B, 3, 32, 32) and out["n_global_crops"] == 2
+    # the SSL index plan honours the collate's upperbound (fixed-size masked-token buffers)
+    from vtp_amd.ssl_engine import build_ssl_indices
+    p = build_ssl_indices(out["masks"].numpy(), B, 16, 4, 4, 1.0, 1.0, upperbound=out["upperbound"])
+    assert p["Tm"] == max(64, (out["upperbound"] + 63) // 64 * 64) and p["n_masked"] == int(out["n_masked_patches"])

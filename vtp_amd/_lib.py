@@ -37,6 +37,7 @@ SIGNATURES = {
     "vtp_gemm_qkv_rope": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "vtp_colsum_bf16_rows": [_P, _I, _P, _P, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],
     "vtp_gather_token_rows": [_P, _P, _P, _I, _I, _P],

@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 
 // out[c'] += sum_r in[r, c]  (bias gradients); block = 64 columns x 256 rows
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ in, int ld, float* __restrict__ out,
-                                                          int R, int C, int csum_H, int in_grp, int in_pre) {
+                                                          int R, int C, int csum_H, int in_grp, int in_pre,
+                                                          const int* __restrict__ rows_dev) {
   __shared__ float part[32][65];
+  if (rows_dev) R = min(R, rows_dev[0]);  // row count from device memory: a captured graph serves any count <= the launch's R
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 256;
   const int tid = threadIdx.x;
   const int cc = (tid & 7) * 8, rr = tid >> 3;
@@ -533,8 +535,15 @@ extern "C" int vtp_colsum_bf16(const void* in, int ld, float* out, int colsum_sw
                                void* stream) {
   VTP_REQUIRE(in && out && R > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "vtp_colsum_bf16: bad argument (C, ld %% 8 == 0)");
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld,
-                     out, R, C, colsum_swiglu_h, in_grp, in_pre);
+                     out, R, C, colsum_swiglu_h, in_grp, in_pre, (const int*)nullptr);
   return check_launch("colsum_bf16");
+}
+
+extern "C" int vtp_colsum_bf16_rows(const void* in, int ld, float* out, const int* n_rows_dev, int R_max, int C, void* stream) {
+  VTP_REQUIRE(in && out && n_rows_dev && R_max > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "vtp_colsum_bf16_rows: bad argument");
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(C, 64), cdiv(R_max, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
+                     ld, out, R_max, C, 0, 0, 0, n_rows_dev);
+  return check_launch("colsum_bf16_rows");
 }
 
 extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,

@@ -195,34 +195,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int IG = (REGION / 4096 >= TN) ? TN : (REGION / 4096);   // 32-column blocks per pass (32 rows x 128 B each)
       static_assert(IG >= 1 && TN % IG == 0, "bad column grouping");
       constexpr int RB = IG * 128, CPR = RB / 16;
+      constexpr int T = 32 * CPR / 64, NPASS = TM * (TN / IG);
       const int r = lane & 31;
+      // the residual rows of pass k + 1 are requested before pass k goes through LDS: one HBM round trip per tile is exposed
+      // instead of one per pass (the dominant cost of this epilogue at K = 768: 8 dependent round trips per 256x256 tile)
+      f32x4 rv[2][T];
+      auto coords = [&](int pass, int t, int& m, int& n) {
+        const int j = pass / (TN / IG), ig = pass % (TN / IG);
+        const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+        m = m0 + wm * WTM + j * 32 + rr;
+        n = n0 + wn * WTN + ig * IG * 32 + c * 4;
+      };
+      auto fetch = [&](int pass, f32x4 (&dst)[T]) {
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+        for (int t = 0; t < T; ++t) {
+          int m, n;
+          coords(pass, t, m, n);
+          dst[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.resid && m < p.M && n < p.N) dst[t] = *(const f32x4*)(p.resid + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n);
+        }
+      };
+      fetch(0, rv[0]);
 #pragma unroll
-        for (int ig = 0; ig < TN / IG; ++ig) {
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int j = pass / (TN / IG), ig = pass % (TN / IG);
+        if (pass + 1 < NPASS) fetch(pass + 1, rv[(pass + 1) & 1]);
 #pragma unroll
-          for (int ii = 0; ii < IG; ++ii)
+        for (int ii = 0; ii < IG; ++ii)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f32x4 v;
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[ig * IG + ii][j][4 * q + e] * p.alpha;
-              *(f32x4*)(reg + r * RB + (((ii * 8 + 2 * q + hi) ^ (r & (CPR - 1))) << 4)) = v;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[ig * IG + ii][j][4 * q + e] * p.alpha;
+            *(f32x4*)(reg + r * RB + (((ii * 8 + 2 * q + hi) ^ (r & (CPR - 1))) << 4)) = v;
+          }
 #pragma unroll
-          for (int t = 0; t < 32 * CPR / 64; ++t) {
-            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
-            f32x4 v = *(const f32x4*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
-            const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + ig * IG * 32 + c * 4;
-            if (m < p.M && n < p.N) {
-              const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
-              if (p.bias) v += *(const f32x4*)(p.bias + n);
-              if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
-              if (p.resid) v += *(const f32x4*)(p.resid + off);
-              *(f32x4*)((float*)p.C + off) = v;
-            }
+        for (int t = 0; t < T; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+          f32x4 v = *(const f32x4*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+          int m, n;
+          coords(pass, t, m, n);
+          if (m < p.M && n < p.N) {
+            const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
+            v += rv[pass & 1][t];
+            *(f32x4*)((float*)p.C + off) = v;
           }
         }
+      }
     }
   }
 #pragma unroll

@@ -250,6 +250,7 @@ class Overlap:
 
 
 OVERLAP = Overlap()
+FUSE_COLSUM = _env_flag("VTP_FUSE_COLSUM")  # bias gradients inside the weight-gradient GEMM (0: separate column-sum launches)
 FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
 WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
@@ -290,8 +291,10 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         if WGRAD_TN:
             # dW[N,K] = dy[M,N]^T x[M,K] straight from the activation layouts (LDS transpose reads inside the GEMM)
             # db = colsum(dy) rides in the wgrad GEMM (fused in the 8-phase kernel, else a column-sum pass inside vtp_gemm_tn)
+            if gb is not None and not FUSE_COLSUM:
+                ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
             kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap,
-                      c_remap=c_remap, a_colsum=gb)
+                      c_remap=c_remap, a_colsum=gb if FUSE_COLSUM else None)
             St = ops.gemm_tn_splits(N, K, M)  # tile-configuration aware (8-phase 256x256 kernel: tiles x splits = 256 CUs)
             if St == 1:
                 ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)

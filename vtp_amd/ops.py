@@ -146,6 +146,10 @@ def colsum_bf16(inp, ld, out, R, C, swiglu_h=0, in_remap=(0, 0)):
     _lib.check(_lib_().vtp_colsum_bf16(_p(inp), ld, _p(out), swiglu_h, in_remap[0], in_remap[1], R, C, _s()), "vtp_colsum_bf16")
 
 
+def colsum_bf16_rows(inp, ld, out, n_rows_dev, R_max, C):
+    _lib.check(_lib_().vtp_colsum_bf16_rows(_p(inp), ld, _p(out), _p(n_rows_dev), R_max, C, _s()), "vtp_colsum_bf16_rows")
+
+
 def gemm_splits(K, splits):
     return _lib_().vtp_gemm_splits(K, splits)
 

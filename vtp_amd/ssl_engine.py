@@ -100,7 +100,7 @@ class DinoHeadEngine:
 
 
 def build_ssl_indices(masks: np.ndarray, B: int, hw: int, n_local: int, hw_local: int, dino_weight: float,
-                      ibot_weight: float, pad_to: int = 64):
+                      ibot_weight: float, pad_to: int = 64, upperbound: Optional[int] = None):
     """Host-side index plan of one SSL batch (the data pipeline produces `masks` on the host anyway).
 
     masks: bool [2B, hw] (global crops, view-major).  Token rows refer to the [.., 1 + hw, D] final-norm streams.
@@ -111,7 +111,13 @@ def build_ssl_indices(masks: np.ndarray, B: int, hw: int, n_local: int, hw_local
     n_g = 2
     flat = np.flatnonzero(masks.reshape(-1))
     n_masked = int(flat.size)
-    Tm = max(pad_to, (n_masked + pad_to - 1) // pad_to * pad_to)
+    if upperbound is not None:  # the reference's fixed-size masked-token buffers (vtp.py:432-439), rounded up to 64 rows
+        if n_masked > upperbound:
+            raise ValueError(f"{n_masked} masked patches exceed upperbound={upperbound}")
+        pad_to, n_cap = 64, int(upperbound)
+    else:
+        n_cap = n_masked
+    Tm = max(pad_to, (n_cap + pad_to - 1) // pad_to * pad_to)
     img_of = flat // hw
     masked_rows = (img_of * N + 1 + flat % hw).astype(np.int32)
     per_img = np.maximum(masks.sum(1), 1)

@@ -125,6 +125,7 @@ class VTPTrainer:
             self.ssl_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
             self.momentum_dev = torch.zeros(4, dtype=F32, device=st.device)
         self._ssl_static = {}
+        self.ssl_bucket = int(os.environ.get("VTP_SSL_BUCKET", "512"))  # masked-token rows are padded to a multiple of this
         self.m = torch.zeros_like(st.flat_p)
         self.v = torch.zeros_like(st.flat_p)
         self.step_no = 0
@@ -200,7 +201,6 @@ class VTPTrainer:
         K, D = head.K, self.trunk.D
         out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
         Tt, Ts, Tm, B2, nl = out["Tt"], out["Ts"], out["Tm"], out["B2"], out["nl"]
-        n_masked = P["plan"]["n_masked"]
         ws = out["ws"]
         t_logits, s_logits = out["teacher_logits"], out["student_logits"]
         probs = ws.get("probs", (Tt, K), BF)
@@ -210,9 +210,9 @@ class VTPTrainer:
         stats = self.center_stats
         stats.zero_()
         ops.colsum_bf16(t_logits, K, stats, B2, K)
-        if n_masked > 0:
-            ops.colsum_bf16(t_logits[B2:], K, stats[K:], n_masked, K)
-        stats[2 * K:2 * K + 1].fill_(float(n_masked))
+        # masked-patch rows: the first n_masked of the Tm padded rows, n_masked read from device memory (graph-replay safe)
+        ops.colsum_bf16_rows(t_logits[B2:], K, stats[K:], P["dev"]["n_masked_i"], Tm, K)
+        stats[2 * K:2 * K + 1].copy_(P["dev"]["n_masked_f"])
         if self.world > 1:
             yield lambda: dist.all_reduce(stats, group=self.group)
         ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
@@ -230,9 +230,13 @@ class VTPTrainer:
         ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_xnf[seg_g.row0:], Ts - nl, D)
         return out
 
-    def prepare_ssl(self, global_crops: torch.Tensor, local_crops: torch.Tensor, masks) -> dict:
-        """Host-side preparation of one SSL batch (index plan + device copies); call outside the timed / captured region.
-        global_crops f32 [2B,3,R,R] (view-major), local_crops f32 [n_local*B,3,r,r], masks bool [2B, (R/16)^2]."""
+    def prepare_ssl(self, global_crops: torch.Tensor, local_crops: torch.Tensor, masks, pad_to: Optional[int] = None,
+                    upperbound: Optional[int] = None) -> dict:
+        """Host-side preparation of one SSL batch (index plan + small H2D copies of the index tensors; no device sync).
+        global_crops f32 [2B,3,R,R] (view-major), local_crops f32 [n_local*B,3,r,r], masks bool [2B, (R/16)^2].
+        The masked-token buffers are padded to a multiple of `pad_to` rows (default self.ssl_bucket = 512; the reference pads
+        to the collate's fixed `upperbound`, vtp.py:432-439 -- pass upperbound=ssl_dict["upperbound"] for exactly that): the
+        step's hipGraph is keyed by the padded size only, the true count travels in device memory."""
         from .ssl_engine import build_ssl_indices
         from .vtp import plan_to_device
         import numpy as np
@@ -241,7 +245,8 @@ class VTPTrainer:
         hw_l = (local_crops.shape[-2] // 16) * (local_crops.shape[-1] // 16)
         n_local = local_crops.shape[0] // B
         m = masks.detach().cpu().numpy().astype(bool) if torch.is_tensor(masks) else np.asarray(masks, bool)
-        plan = build_ssl_indices(m, B, hw, n_local, hw_l, self.dino_weight, self.ibot_weight)
+        plan = build_ssl_indices(m, B, hw, n_local, hw_l, self.dino_weight, self.ibot_weight,
+                                 pad_to=int(pad_to or self.ssl_bucket), upperbound=upperbound)
         dev = self.store.device
         return dict(**{"global": global_crops, "local": local_crops}, masks=torch.as_tensor(m.astype(np.uint8), device=dev),
                     plan=plan, dev=plan_to_device(plan, dev))
@@ -485,7 +490,7 @@ class VTPTrainer:
         skey = None
         if ssl is not None:
             pl = ssl["plan"]
-            skey = (tuple(ssl["global"].shape), tuple(ssl["local"].shape), pl["Ts"], pl["n_masked"])
+            skey = (tuple(ssl["global"].shape), tuple(ssl["local"].shape), pl["Ts"])  # Ts: padded (bucketed) row count
         key = (tuple(images.shape), None if text is None else tuple(text.shape), skey)
         plan = self._graphs.get(key)
         if plan is None:

@@ -122,6 +122,10 @@ def plan_to_device(plan, device):
     """int32 / f32 index tensors of one SSL batch on the device (done outside any graph capture)."""
     d = {k: torch.as_tensor(plan[k], device=device) for k in ("teacher_src", "student_local_src", "student_global_src", "t0", "t1")}
     d["w"] = torch.as_tensor(plan["w"], device=device)
+    # the masked-token count travels in device memory: kernels read it there, so one captured graph serves every mask draw
+    # that fits the same padded buffers
+    d["n_masked_i"] = torch.tensor([plan["n_masked"]], dtype=torch.int32, device=device)
+    d["n_masked_f"] = torch.tensor([float(plan["n_masked"])], dtype=torch.float32, device=device)
     return d
 
 
