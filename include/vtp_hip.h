@@ -154,6 +154,8 @@ int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream
 
 /* PixelShuffle(16) (pixel_decoder.py:160): t bf16 [B*h*w, 768] token-major -> img f32 [B,3,16h,16w]. */
 int vtp_pixel_shuffle16(const void* t, float* img, int B, int h, int w, void* stream);
+/* backward of F.pixel_shuffle(., 16) (pixel_decoder.py:160): image gradient f32 [B,3,16h,16w] -> token-major bf16 [B*h*w, 768] */
+int vtp_pixel_unshuffle16(const float* d_img, void* dt, int B, int h, int w, void* stream);
 /* L1 reconstruction loss on the token-major decoder output: loss_sum[0] += sum |shuffle(t) - target|;
  * dt bf16 [B*h*w,768] = sign(shuffle(t) - target) * gscale  (gscale = loss_weight / numel). */
 int vtp_l1_loss_fwd_bwd(const void* t, const float* target, void* dt, float* loss_sum, int B, int h, int w,

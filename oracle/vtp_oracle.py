@@ -253,11 +253,13 @@ def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True) 
     return F.normalize(x, dim=-1) if normalize else x
 
 
-def clip_image_feature(sd, img: Tensor, num_heads: int, normalize: bool = True) -> Tensor:
-    """VTPModel.get_clip_image_feature -- modeling_vtp.py:244-276 with the defaults
-    vision_bottleneck_ae_only=True (=> no bottleneck) and vision_clip_feat='cls'."""
-    out = trunk_forward(sd, img, num_heads, use_bottleneck=False)
-    f = F.linear(out["x_norm_clstoken"], sd["visual_proj.weight"])
+def clip_image_feature(sd, img: Tensor, num_heads: int, normalize: bool = True, clip_feat: str = "cls",
+                       ae_only: bool = True) -> Tensor:
+    """VTPModel.get_clip_image_feature -- modeling_vtp.py:244-276 (defaults vision_bottleneck_ae_only=True => no
+    bottleneck, vision_clip_feat='cls'; 'pooled' = mean of the patch tokens, :269)."""
+    out = trunk_forward(sd, img, num_heads, use_bottleneck=not ae_only)
+    feat = out["x_norm_clstoken"] if clip_feat == "cls" else out["x_norm_patchtokens"].mean(dim=1)
+    f = F.linear(feat, sd["visual_proj.weight"])
     return F.normalize(f, dim=-1) if normalize else f
 
 

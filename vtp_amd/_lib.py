@@ -28,6 +28,7 @@ SIGNATURES = {
     "vtp_swiglu_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "vtp_gelu_bwd": [_P, _P, _P, _L, _P],
     "vtp_pixel_shuffle16": [_P, _P, _I, _I, _I, _P],
+    "vtp_pixel_unshuffle16": [_P, _P, _I, _I, _I, _P],
     "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "vtp_adamw": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "vtp_adamw_dev": [_P, _P, _P, _P, _P, _L, _P, _P],

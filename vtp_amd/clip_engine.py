@@ -83,10 +83,12 @@ class ClipHead:
 
     def __init__(self, store: ParamStore, vproj, Dv: int, Dt: int):
         self.store, self.vproj, self.Dv, self.Dt = store, vproj, Dv, Dt
+        self.fused_ok = vproj.K == Dv  # cls token of the un-bottlenecked trunk output (the GEMMs below read K = Dv columns)
         self.ws = Workspace(store.device)
 
     def image_features(self, xnf: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """cls rows of the final-norm token matrix (bf16 [B*N, Dv]) -> un-normalised image features f32 [B, Dt]."""
+        assert self.fused_ok, "ClipHead: visual_proj input width != trunk width (bottlenecked CLIP feature): use the autograd path"
         f = self.ws.get(f"f_img{B}", (B, self.Dt), F32)
         ops.gemm_nt(xnf, self.vproj.w, f, M=B, N=self.Dt, K=self.Dv, lda=N * self.Dv, epi=EPI_F32)
         return f

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
 }
 
 // PixelShuffle(16) of the token-major decoder output (+ optional fused L1 loss / gradient).
-template <int MODE>  // 0: write f32 image; 1: L1 loss + dt
+template <int MODE>  // 0: write f32 image; 1: L1 loss + dt; 2: dt = un-shuffled image gradient (`img` holds d_img)
 __global__ __launch_bounds__(256) void shuffle16_kernel(const bf16* __restrict__ t, float* __restrict__ img,
                                                         const float* __restrict__ target, bf16* __restrict__ dt,
                                                         float* __restrict__ loss_sum, int B, int h, int w, float gscale) {
@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256) void shuffle16_kernel(const bf16* __restrict__
     const long ioff = ((b * 3 + c) * H + (y * 16 + i)) * (long)W + x * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (MODE == 2) {  // backward of PixelShuffle: gather the f32 image gradient into the token-major bf16 layout
+        *(bf16x4*)(dt + toff + 4 * q) = __builtin_convertvector(*(const f32x4*)(img + ioff + 4 * q), bf16x4);
+        continue;
+      }
       f32x4 v = __builtin_convertvector(*(const bf16x4*)(t + toff + 4 * q), f32x4);
       if (MODE == 0) {
         *(f32x4*)(img + ioff + 4 * q) = v;
@@ -605,6 +609,13 @@ extern "C" int vtp_pixel_shuffle16(const void* t, float* img, int B, int h, int 
   hipLaunchKernelGGL(shuffle16_kernel<0>, dim3(grid_for((long)B * h * w * 48)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)t, img, nullptr, nullptr, nullptr, B, h, w, 0.f);
   return check_launch("pixel_shuffle16");
+}
+
+extern "C" int vtp_pixel_unshuffle16(const float* d_img, void* dt, int B, int h, int w, void* stream) {
+  VTP_REQUIRE(d_img && dt && B > 0 && h > 0 && w > 0, "vtp_pixel_unshuffle16: bad argument");
+  hipLaunchKernelGGL(shuffle16_kernel<2>, dim3(grid_for((long)B * h * w * 48)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)nullptr, const_cast<float*>(d_img), nullptr, (bf16*)dt, nullptr, B, h, w, 0.f);
+  return check_launch("pixel_unshuffle16");
 }
 
 extern "C" int vtp_l1_loss_fwd_bwd(const void* t, const float* target, void* dt, float* loss_sum, int B, int h, int w,

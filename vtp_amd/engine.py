@@ -177,6 +177,16 @@ class ParamStore:
     def zero_grad(self):
         self.flat_g.zero_()
 
+    def sync_grad_views(self):
+        """Every parameter's .grad must be its slice of the flat gradient buffer (the engines accumulate there).  A torch
+        optimizer's zero_grad(set_to_none=True) drops the views: re-attach them, zeroed ("None" means a fresh gradient)."""
+        for n, prm in self.params.items():
+            if prm.grad is None and prm.requires_grad:
+                o, k = self.offsets[n]
+                view = self.flat_g[o:o + k].view(prm.shape)
+                view.zero_()
+                prm.grad = view
+
 
 # =====================================================================================================================
 # buffers

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from .config import VTPConfig, swiglu_hidden
 from .engine import BF, F32, DecoderEngine, ParamStore, TrunkEngine
@@ -233,6 +234,15 @@ class VTPModel(nn.Module):
             self.refresh_weights()
         return st
 
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients live in ONE flat buffer that every `p.grad` views (the fused optimizer / RCCL buckets use it directly):
+        zeroed in place, the views stay attached whatever `set_to_none` says."""
+        if self._store is not None:
+            self._store.zero_grad()
+            self._store.sync_grad_views()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._store is not None:
@@ -260,9 +270,16 @@ class VTPModel(nn.Module):
             raise ValueError(f"image must be [B,3,H,W] with H,W multiples of 16, got {tuple(image.shape)}")
         return image.detach().to(dtype=torch.float32).contiguous()
 
-    @torch.no_grad()
     def get_reconstruction_latents(self, image: torch.Tensor) -> torch.Tensor:
-        """modeling_vtp.py:337-360 -> [B, 64, H/16, W/16] (f32)."""
+        """modeling_vtp.py:337-360 -> [B, 64, H/16, W/16] (f32).  Differentiable (autograd.EncodeLatents) when autograd is
+        recording and the module is in training mode; the inference path otherwise."""
+        if ag.grad_mode(self):
+            self._img(image)
+            return ag.EncodeLatents.apply(image, ag.anchor(self), self, "ag.rec")
+        return self._latents_nograd(image)
+
+    @torch.no_grad()
+    def _latents_nograd(self, image: torch.Tensor) -> torch.Tensor:
         self._fresh()
         img = self._img(image)
         B, _, H, W = img.shape
@@ -270,11 +287,16 @@ class VTPModel(nn.Module):
         lat = self._trunk.latents(out_f32=True)  # [B*hw, 64]
         return lat.view(B, (H // 16) * (W // 16), -1).transpose(1, 2).reshape(B, -1, H // 16, W // 16).clone()
 
-    @torch.no_grad()
     def get_latents_decoded_images(self, latents: torch.Tensor) -> torch.Tensor:
-        """modeling_vtp.py:362-377 -> [B, 3, H, W] (f32)."""
+        """modeling_vtp.py:362-377 -> [B, 3, H, W] (f32).  Differentiable in training mode (autograd.DecodeLatents)."""
         if self.pixel_decoder is None:
             raise RuntimeError("Reconstruction not enabled. Set train_reconstruction=True in config.")
+        if ag.grad_mode(self):
+            return ag.DecodeLatents.apply(latents, ag.anchor(self), self)
+        return self._decode_nograd(latents)
+
+    @torch.no_grad()
+    def _decode_nograd(self, latents: torch.Tensor) -> torch.Tensor:
         self._fresh()
         B, C, h, w = latents.shape
         lat = latents.detach().reshape(B, C, h * w).transpose(1, 2).to(torch.bfloat16).contiguous().view(B * h * w, C)
@@ -335,15 +357,38 @@ class VTPModel(nn.Module):
             outs.append((patch, cls_t) if return_class_token else patch)
         return tuple(outs)
 
-    @torch.no_grad()
     def get_clip_image_feature(self, image: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-        """modeling_vtp.py:244-276."""
+        """modeling_vtp.py:244-276: cls (or mean-pooled patch) token of the final-norm trunk output -- bottlenecked first unless
+        vision_bottleneck_ae_only -- through visual_proj, optionally L2-normalised.  Differentiable in training mode."""
         if self.visual_proj is None:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
+        c = self.config
+        general = c.vision_clip_feat != "cls" or not c.vision_bottleneck_ae_only
+        if ag.grad_mode(self) or general:
+            # tokens from the trunk kernels; the [B, D] pooling / projection / normalisation heads are torch ops on the fp32
+            # parameters (autograd-native; the reference does the same arithmetic, modeling_vtp.py:262-276)
+            self._img(image)
+            if ag.grad_mode(self):
+                tokens = ag.TrunkTokens.apply(image, ag.anchor(self), self, "ag.clip")
+            else:
+                with torch.no_grad():
+                    self._fresh()
+                    img = self._img(image)
+                    tokens = self._trunk.forward(img, train=False).float().view(img.shape[0], -1, c.vision_embed_dim)
+            with torch.set_grad_enabled(ag.grad_mode(self)):
+                pooled, patches = tokens[:, 0], tokens[:, 1:]
+                if not c.vision_bottleneck_ae_only and hasattr(self.trunk, "feature_bottleneck"):
+                    wb = self.trunk.feature_bottleneck.weight
+                    pooled, patches = torch.nn.functional.linear(pooled, wb), torch.nn.functional.linear(patches, wb)
+                feat = pooled if c.vision_clip_feat == "cls" else patches.mean(dim=1)
+                feat = torch.nn.functional.linear(feat, self.visual_proj.weight)
+                return torch.nn.functional.normalize(feat, dim=-1) if normalize else feat
+        return self._clip_image_nograd(image, normalize)
+
+    @torch.no_grad()
+    def _clip_image_nograd(self, image: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         self._fresh()
         c = self.config
-        if c.vision_clip_feat != "cls" or not c.vision_bottleneck_ae_only:
-            raise NotImplementedError("only vision_clip_feat='cls' with vision_bottleneck_ae_only=True is implemented")
         img = self._img(image)
         B, _, H, W = img.shape
         N = (H // 16) * (W // 16) + 1
@@ -354,26 +399,35 @@ class VTPModel(nn.Module):
             f, _ = self._clip.normalize(f, "img")
         return f.clone()
 
-    @torch.no_grad()
     def get_clip_text_feature(self, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-        """modeling_vtp.py:278-310."""
+        """modeling_vtp.py:278-310.  Differentiable in training mode (autograd.TextFeature)."""
         if not self.config.train_clip:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
-        self._fresh()
         if text.ndim != 2 or text.shape[1] != self.config.text_context_length:
             raise ValueError(f"text must be [B, {self.config.text_context_length}] token ids, got {tuple(text.shape)}")
+        if ag.grad_mode(self):
+            ids = text.detach().to(dtype=torch.int64).contiguous()
+            f = ag.TextFeature.apply(ids, ag.anchor(self), self)
+            return torch.nn.functional.normalize(f, dim=-1) if normalize else f
+        return self._clip_text_nograd(text, normalize)
+
+    @torch.no_grad()
+    def _clip_text_nograd(self, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        self._fresh()
         ids = text.detach().to(dtype=torch.int64).contiguous()
         f = self._text.forward(ids, train=False)
         if normalize:
             f, _ = self._clip.normalize(f, "txt")
         return f.clone()
 
-    @torch.no_grad()
     def get_clip_logits(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """modeling_vtp.py:312-333 (the [B_img, B_txt] logits GEMM is host-level glue on two small normalised matrices)."""
         i = self.get_clip_image_feature(image, normalize=True)
         t = self.get_clip_text_feature(text, normalize=True)
-        logits = self.logit_scale.exp() * i @ t.T
+        with torch.set_grad_enabled(ag.grad_mode(self)):
+            logits = self.logit_scale.exp() * i @ t.T
+            if self.logit_bias is not None:
+                logits = logits + self.logit_bias
         return logits, logits.T
 
     def forward(self, image=None, text=None, forward_type: str = "clip"):

@@ -119,6 +119,10 @@ def pixel_shuffle16(t, img, B, h, w):
     _lib.check(_lib_().vtp_pixel_shuffle16(_p(t), _p(img), B, h, w, _s()), "vtp_pixel_shuffle16")
 
 
+def pixel_unshuffle16(d_img, dt, B, h, w):
+    _lib.check(_lib_().vtp_pixel_unshuffle16(_p(d_img), _p(dt), B, h, w, _s()), "vtp_pixel_unshuffle16")
+
+
 def l1_loss_fwd_bwd(t, target, dt, loss_sum, B, h, w, gscale):
     _lib.check(_lib_().vtp_l1_loss_fwd_bwd(_p(t), _p(target), _p(dt), _p(loss_sum), B, h, w, gscale, _s()),
                "vtp_l1_loss_fwd_bwd")

@@ -139,6 +139,27 @@ class VTPTrainer:
         self.hyper = torch.zeros(8, dtype=F32, device=st.device)
         self.use_graphs = use_graphs
         self._graphs = {}
+        if self.text is not None and (model.config.vision_clip_feat != "cls" or not model.config.vision_bottleneck_ae_only):
+            self._clip_unsupported = ("the fused trainer implements the cls-token / un-bottlenecked CLIP image feature only "
+                                      "(vision_clip_feat='cls', vision_bottleneck_ae_only=True); other settings train through "
+                                      "the autograd path (model(...); loss.backward())")
+        else:
+            self._clip_unsupported = None
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data-parallel replicas must start from identical state (what DDP's constructor does with its parameter / buffer
+        broadcast): rank 0's fp32 masters (student AND EMA teacher), Adam moments and SSL centres go to every rank."""
+        if self.world == 1:
+            return
+        dist, st = self.bucketer.dist, self.store
+        bufs = [st.flat_p, self.m, self.v]
+        if self.ssl_head is not None:
+            bufs += [self.center_dino, self.center_ibot]
+        for b in bufs:
+            dist.broadcast(b, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        st.prep()
+        self.model._pver = self.model._param_version()
 
     # gradient buckets in backward-completion order
     def _plan_buckets(self):
@@ -377,6 +398,10 @@ class VTPTrainer:
             main.wait_stream(T)
             yield held
         yield ["dec_head"]
+        if text is None and ssl is None:
+            # no head writes the cls rows of d_xnf on this step: clear what an earlier step with another objective set left there
+            # (the workspace is keyed by shape, not by objectives)
+            self.trunk.d_xnf_buffer().zero_()
         yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
         yield ["trunk_head", "FINAL"]
         # ---- optimizer (after every bucket has been reduced)
@@ -387,7 +412,7 @@ class VTPTrainer:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
             from .vtp import _range
-            for t_pref, s_pref in (("teacher_trunk.", "trunk."), ("teacher_dino_head.", "dino_head.")):
+            for t_pref, s_pref in self.model.ema_pairs():  # trunk, proj (legacy teacher_proj, vtp.py:396-398), dino_head
                 (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
                 ops.ema_dev(st.flat_p[tlo:thi], st.flat_p[slo:shi], thi - tlo, self.momentum_dev)
         st.prep()
@@ -446,6 +471,8 @@ class VTPTrainer:
             raise RuntimeError("SSL needs a vtp_amd.VTP model (DINO head + EMA teacher)")
         if text is not None and self.text is None:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
+        if text is not None and self._clip_unsupported:
+            raise NotImplementedError(self._clip_unsupported)
         B, _, H, W = images.shape
         self._set_hyper()
         if self.use_graphs:
@@ -484,6 +511,7 @@ class VTPTrainer:
         if self.ssl_head is not None and "center_dino" in sd:
             self.center_dino.copy_(sd["center_dino"])
             self.center_ibot.copy_(sd["center_ibot"])
+        self.sync_replicas()
 
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
     def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from .config import VTPConfig
 from .engine import BF, F32, OVERLAP, TrunkEngine
@@ -56,9 +57,50 @@ class VTP(VTPModel):
             self.dino_head.last_layer.weight_g.fill_(1.0)
         self.teacher_trunk = copy.deepcopy(self.trunk)
         self.teacher_dino_head = copy.deepcopy(self.dino_head)
-        for p in list(self.teacher_trunk.parameters()) + list(self.teacher_dino_head.parameters()):
+        # legacy layout: the image projection is `proj` with an EMA copy `teacher_proj` (vtp.py:217,249); the HF class calls
+        # it `visual_proj`.  One parameter under the HF name, `proj` as an alias, `teacher_proj` as its own frozen parameter.
+        self.teacher_proj = copy.deepcopy(self.visual_proj) if self.visual_proj is not None else None
+        frozen = list(self.teacher_trunk.parameters()) + list(self.teacher_dino_head.parameters())
+        if self.teacher_proj is not None:
+            frozen += list(self.teacher_proj.parameters())
+        for p in frozen:
             p.requires_grad = False
         self.enable_teacher = True
+        self.output_dict = True  # training.clip_output_dict (vtp.py:189)
+
+    # ------------------------------------------------------------------------------------------------ legacy layout
+    @property
+    def proj(self):
+        return self.visual_proj
+
+    @property
+    def transformer(self):
+        return getattr(self, "text_transformer", None)
+
+    _LEGACY_PREFIXES = (("proj.", "visual_proj."), ("transformer.", "text_transformer."))
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """Accepts the HF-layout keys (VTPModel) and the legacy training-class layout (vtp/models/vtp.py: `proj`,
+        `teacher_proj`, `transformer.resblocks.*`) -- a checkpoint of the reference's `VTP` loads with strict=True."""
+        sd = {}
+        for k, v in state_dict.items():
+            for old, new in self._LEGACY_PREFIXES:
+                if k.startswith(old):
+                    k = new + k[len(old):]
+                    break
+            sd[k] = v
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def legacy_state_dict(self) -> Dict[str, torch.Tensor]:
+        """state_dict under the reference legacy class's key names (inverse of the mapping load_state_dict applies)."""
+        out = {}
+        for k, v in self.state_dict().items():
+            for old, new in self._LEGACY_PREFIXES:
+                if k.startswith(new):
+                    k = old + k[len(new):]
+                    break
+            out[k] = v
+        return out
 
     # ------------------------------------------------------------------------------------------------ engine
     def _build_extra_engines(self, st):
@@ -75,22 +117,103 @@ class VTP(VTPModel):
     def update_teacher(self, momentum: float):
         """teacher = m * teacher + (1 - m) * student over trunk and dino_head parameters (vtp.py:388-401): two fused
         launches over contiguous ranges of the flat parameter buffer."""
+        if not self.enable_teacher:
+            return
         st = self._engine()
-        for t_pref, s_pref in (("teacher_trunk.", "trunk."), ("teacher_dino_head.", "dino_head.")):
+        for t_pref, s_pref in self.ema_pairs():
             (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
             assert thi - tlo == shi - slo
             ops.ema(st.flat_p[tlo:thi], st.flat_p[slo:shi], thi - tlo, momentum)
         st.prep()
         self._pver = self._param_version()
 
-    @torch.no_grad()
+    def ema_pairs(self):
+        """(teacher prefix, student prefix) of every EMA-tracked parameter group (vtp.py:388-401: trunk, proj, dino_head)"""
+        pairs = [("teacher_trunk.", "trunk.")]
+        if self.teacher_proj is not None:
+            pairs.append(("teacher_proj.", "visual_proj."))
+        pairs.append(("teacher_dino_head.", "dino_head."))
+        return pairs
+
+    # ------------------------------------------------------------------------------------------------ legacy forward surface
+    def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """vtp.py:275-291 (default normalize=False, unlike the HF class)."""
+        return self.get_clip_image_feature(image, normalize=normalize)
+
+    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """vtp.py:293-312."""
+        return self.get_clip_text_feature(text, normalize=normalize)
+
+    def get_logits(self, image: torch.Tensor, text: torch.Tensor):
+        """vtp.py:314-321."""
+        return self.get_clip_logits(image, text)
+
+    def forward_clip(self, image: Optional[torch.Tensor], text: Optional[torch.Tensor]):
+        """vtp.py:340-360."""
+        image_features = self.encode_image(image, normalize=True) if image is not None else None
+        text_features = self.encode_text(text, normalize=True) if text is not None else None
+        with torch.set_grad_enabled(ag.grad_mode(self)):
+            scale = self.logit_scale.exp()
+        if self.output_dict:
+            out = {"image_features": image_features, "text_features": text_features, "logit_scale": scale}
+            if self.logit_bias is not None:
+                out["logit_bias"] = self.logit_bias
+            return out
+        if self.logit_bias is not None:
+            return image_features, text_features, scale, self.logit_bias
+        return image_features, text_features, scale
+
+    def forward_reconstruction(self, reconstruction_image: torch.Tensor):
+        """vtp.py:362-363 -> get_reconstruction_outputs (vtp.py:487-512)."""
+        if self.pixel_decoder is None:
+            return {}
+        lat = self.get_reconstruction_latents(reconstruction_image)
+        return {"reconstructed_image": self.get_latents_decoded_images(lat), "target_image": reconstruction_image}
+
+    def forward(self, image=None, text=None, ssl_dict: Optional[dict] = None, reconstruction_image=None,
+                forward_type: str = "clip"):
+        """The legacy training forward (vtp.py:323-338): forward_type in {clip, ssl, rec}; differentiable in training mode."""
+        assert forward_type in ["clip", "ssl", "rec"], "Invalid forward type"
+        if forward_type == "clip":
+            return self.forward_clip(image, text)
+        if forward_type == "ssl":
+            return self.forward_ssl_learning(**ssl_dict)
+        return self.forward_reconstruction(reconstruction_image)
+
     def forward_ssl_learning(self, global_crops, n_global_crops, mask_indices_list, n_masked_patches, upperbound,
-                             local_crops, masks):
-        """Inference-mode SSL forward with the legacy signature/outputs (vtp.py:365-385): returns
-        (teacher_outputs, student_outputs) with the reference's dict keys; logits are f32 copies of the bf16 kernels'
-        outputs.  (Training goes through VTPTrainer.step(..., ssl=...).)"""
+                             local_crops, masks, masks_weight=None):
+        """SSL forward with the legacy signature / outputs (vtp.py:365-385): (teacher_outputs, student_outputs) with the
+        reference's dict keys; logits are f32 copies of the bf16 kernels' outputs.  In training mode the student outputs are
+        differentiable (autograd.SSLStudent); the fused training step is VTPTrainer.step(..., ssl=...)."""
         if n_global_crops != 2:
             raise NotImplementedError("n_global_crops must be 2")
+        if ag.grad_mode(self):
+            return self._forward_ssl_autograd(global_crops, local_crops, masks, n_masked_patches, upperbound)
+        return self._forward_ssl_nograd(global_crops, n_global_crops, mask_indices_list, n_masked_patches, upperbound, local_crops,
+                                        masks)
+
+    def _forward_ssl_autograd(self, global_crops, local_crops, masks, n_masked_patches, upperbound):
+        self._fresh()
+        B2 = global_crops.shape[0]
+        B = B2 // 2
+        hw = (global_crops.shape[-2] // 16) * (global_crops.shape[-1] // 16)
+        hw_l = (local_crops.shape[-2] // 16) * (local_crops.shape[-1] // 16)
+        n_local = local_crops.shape[0] // B
+        plan = build_ssl_indices(masks.detach().cpu().numpy().astype(bool), B, hw, n_local, hw_l, 1.0, 1.0, pad_to=8)
+        assert plan["n_masked"] == int(n_masked_patches) <= int(upperbound)
+        m8 = masks.to(self._store.device).to(torch.uint8).contiguous()
+        s_loc, s_glob, s_cls, s_patch, t_logits = ag.SSLStudent.apply(ag.anchor(self), self, self._img(global_crops),
+                                                                      self._img(local_crops), m8, plan)
+        nm = plan["n_masked"]
+        teacher_outputs = {"teacher_cls_tokens_after_head": t_logits[:B2], "n_masked_patches": n_masked_patches,
+                           "masked_teacher_patch_tokens_after_head": t_logits[B2:B2 + nm]}
+        student_outputs = {"student_local_cls_tokens_after_head": s_loc, "student_global_cls_tokens_after_head": s_glob,
+                           "student_global_cls_tokens": s_cls, "student_global_masked_patch_tokens_after_head": s_patch}
+        return teacher_outputs, student_outputs
+
+    @torch.no_grad()
+    def _forward_ssl_nograd(self, global_crops, n_global_crops, mask_indices_list, n_masked_patches, upperbound, local_crops,
+                            masks):
         self._fresh()
         B2 = global_crops.shape[0]
         B = B2 // 2
