@@ -75,6 +75,22 @@ int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc
 int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* C, int ldc, int M, int N, int K,
                       const int* rope_pos, const void* rope_sin, const void* rope_cos, int rope_cols, void* stream);
 
+/* ---- residual-wiring extras of SelfAttentionBlock (block.py:20-118,207-289; misc.py:7-26) ---------------------------------
+ * Stochastic depth ("sample drop"): the residual branch runs on a random subset of the images of a segment (an image = N
+ * consecutive token rows) and is added back with alpha = batch / kept (torch.index_add(x, 0, residual, idx, alpha), block.py:216-232).
+ *   vtp_gather_image_rows : dst[i*N + t, :] = src[idx[i]*N + t, :] as f32 (dst, optional) and/or as bf16(scale * .) (dst_bf16, optional)
+ *   vtp_scatter_image_rows: dst[idx[i]*N + t, :] = (accumulate ? dst : 0) + alpha * src[i*N + t, :]      (idx entries are distinct)
+ * LayerScale (y = x + gamma * f(x), misc.py:24-25) backward without storing f: with G = dy^T x_in (the unscaled weight-gradient
+ * GEMM) and cs = colsum(dy):  dW += gamma (.) G,  db += gamma (.) cs,  dgamma += rowsum(W (.) G) + b (.) cs;
+ * vtp_scaled_transpose writes bf16 (gamma (.) W)^T, the dgrad operand. */
+int vtp_gather_image_rows(const float* src, const int* img_idx, float* dst, void* dst_bf16, int n_img, long N, int D, float scale,
+                          void* stream);
+int vtp_scatter_image_rows(const float* src, const int* img_idx, float* dst, int n_img, long N, int D, float alpha, int accumulate,
+                           void* stream);
+int vtp_layerscale_wgrad(const float* G, const float* W, const float* bias, const float* colsum, const float* gamma, float* dW,
+                         float* db, float* dgamma, int N, int K, void* stream);
+int vtp_scaled_transpose(const float* W, const float* gamma, void* dstT, int N, int K, void* stream);
+
 /* ---- normalisation ---------------------------------------------------------------------------
  * kind 0 = RMSNorm (normalization.py:17-22, eps 1e-5, no bias), 1 = LayerNorm (vision_transformer.py:30-34
  * eps 1e-6 decoder; normalization.py:25-31 text).  x f32 [M, D] -> y bf16 [M, D]; stats f32 [M,2] = (mean, rstd).

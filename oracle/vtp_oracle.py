@@ -118,17 +118,32 @@ def swiglu_ffn(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
     return F.linear(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
 
 
-def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, norm: str) -> Tensor:
-    """SelfAttentionBlock eval / drop_ratio==0 branch -- block.py:290-296 (LayerScale is Identity
-    unless init_values, block.py:173,185)."""
+def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, norm: str, drop=None) -> Tensor:
+    """SelfAttentionBlock._forward -- block.py:207-233.  Default: the eval / drop_ratio == 0 branch (:290-296); LayerScale
+    (misc.py:24-25) is applied when the checkpoint has `ls1.gamma` / `ls2.gamma` (Identity otherwise, block.py:173,185).
+    drop = (idx1, alpha1, idx2, alpha2): the training branch with stochastic depth for GIVEN image subsets (the reference
+    draws them with torch.randperm, get_branges_scales block.py:20-118): the residual branch runs on x[idx] and is added back
+    with torch.index_add(..., alpha=batch / kept) (:213-232)."""
     def nrm(t, name):
         if norm == "rmsnorm":
             return rmsnorm(t, sd[pre + name + ".weight"], 1e-5)
         return layernorm(t, sd[pre + name + ".weight"], sd[pre + name + ".bias"], 1e-6)
 
-    x = x + self_attention(nrm(x, "norm1"), sd, pre + "attn.", num_heads, rope)
-    x = x + swiglu_ffn(nrm(x, "norm2"), sd, pre + "mlp.")
-    return x
+    ls1 = sd.get(pre + "ls1.gamma")
+    ls2 = sd.get(pre + "ls2.gamma")
+    f1 = (lambda t: t * ls1) if ls1 is not None else (lambda t: t)
+    f2 = (lambda t: t * ls2) if ls2 is not None else (lambda t: t)
+    if drop is None:
+        x = x + f1(self_attention(nrm(x, "norm1"), sd, pre + "attn.", num_heads, rope))
+        x = x + f2(swiglu_ffn(nrm(x, "norm2"), sd, pre + "mlp."))
+        return x
+    idx1, a1, idx2, a2 = drop
+    r1 = self_attention(nrm(x[idx1], "norm1"), sd, pre + "attn.", num_heads, rope)
+    # .to(x.dtype): a no-op in fp32; under bf16 autocast the branch output is bf16 while the stream is fp32 and index_add would
+    # raise (the reference as written cannot run this branch under autocast with an fp32 stream) -- needed for the tests' E_ref
+    x = torch.index_add(x, 0, idx1, f1(r1).to(x.dtype), alpha=a1)
+    r2 = swiglu_ffn(nrm(x[idx2], "norm2"), sd, pre + "mlp.")
+    return torch.index_add(x, 0, idx2, f2(r2).to(x.dtype), alpha=a2)
 
 
 def _depth(sd: Dict[str, Tensor], pre: str) -> int:
@@ -148,7 +163,7 @@ def patch_embed(img: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottleneck: bool = True,
-                  masks: Optional[Tensor] = None, pre: str = "trunk.") -> Dict[str, Tensor]:
+                  masks: Optional[Tensor] = None, pre: str = "trunk.", drop=None) -> Dict[str, Tensor]:
     """DinoVisionTransformerWithBottleneck.forward(is_training=True) for ONE resolution --
     vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79."""
     x = patch_embed(img, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
@@ -162,7 +177,7 @@ def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottle
     x = torch.cat([cls.expand(B, -1, -1), x], dim=1)  # :210-217 (no storage tokens)
     rope = rope_table(H, W, sd[pre + "rope_embed.periods"])
     for i in range(_depth(sd, pre + "blocks.")):
-        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm")
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm", drop=None if drop is None else drop[i])
     xn = rmsnorm(x, sd[pre + "norm.weight"], 1e-5)  # :246
     cls_t, patch_t = xn[:, 0], xn[:, 1:]
     if use_bottleneck and (pre + "feature_bottleneck.weight") in sd:  # bottleneck.py:66-79
@@ -208,14 +223,14 @@ def reconstruction_latents(sd, img, num_heads) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # pixel decoder -- vtp/models/decoders/pixel_decoder.py:134-162
 # --------------------------------------------------------------------------------------------
-def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.") -> Tensor:
+def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.", drop=None) -> Tensor:
     B, _, H, W = latents.shape
     x = F.conv2d(latents, sd[pre + "proj_in.weight"], sd[pre + "proj_in.bias"])  # :138
     D = x.shape[1]
     x = x.flatten(2).transpose(1, 2)  # :141
     rope = rope_table(H, W, sd[pre + "rope_embed.periods"])  # :144
     for i in range(_depth(sd, pre + "blocks.")):
-        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm")
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm", drop=None if drop is None else drop[i])
     x = layernorm(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-6)  # :151
     x = x.transpose(1, 2).reshape(B, D, H, W)  # :154
     x = F.conv2d(x, sd[pre + "proj_out.weight"], sd[pre + "proj_out.bias"])  # :157

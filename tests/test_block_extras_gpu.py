@@ -1,0 +1,157 @@
+"""SelfAttentionBlock residual-wiring extras: LayerScale forward + backward (misc.py:7-26) and stochastic
+depth (block.py:20-118,207-289) -- kernels vs torch, then the whole rec train step (trunk + pixel decoder) against the oracle's
+autograd, the oracle being pinned to the REAL reference for exactly these branches (tests/test_oracle_vs_reference.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def relF(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_block_extra_kernels_vs_torch():
+    from vtp_amd import ops as o
+    g = torch.Generator(device=DEV).manual_seed(2)
+    B, N, D = 7, 17, 128
+    x = torch.randn(B * N, D, device=DEV, generator=g)
+    idx = torch.tensor([5, 0, 3, 6], dtype=torch.int32, device=DEV)
+    dst = torch.full((4 * N, D), float("nan"), device=DEV)
+    dst_b = torch.full((4 * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.gather_image_rows(x, idx, dst, dst_b, 4, N, D, 1.75)
+    ref = x.view(B, N, D)[idx.long()].reshape(4 * N, D)
+    assert torch.equal(dst, ref) and torch.equal(dst_b, (ref * 1.75).to(torch.bfloat16))
+    y = x.clone()
+    src = torch.randn(4 * N, D, device=DEV, generator=g)
+    o.scatter_image_rows(src, idx, y, 4, N, D, 1.75, True)
+    ref_y = torch.index_add(x.view(B, N, D), 0, idx.long(), src.view(4, N, D), alpha=1.75).view(-1, D)
+    assert torch.allclose(y, ref_y, rtol=1e-6, atol=1e-6)
+    o.scatter_image_rows(src, idx, y, 4, N, D, 1.0, False)
+    assert torch.equal(y.view(B, N, D)[idx.long()].reshape(-1, D), src) and torch.equal(y.view(B, N, D)[1], ref_y.view(B, N, D)[1])
+    # LayerScale wgrad finish + scaled transpose
+    Nn, K = 96, 200
+    G = torch.randn(Nn, K, device=DEV, generator=g)
+    W = torch.randn(Nn, K, device=DEV, generator=g)
+    bias, cs, gamma = (torch.randn(Nn, device=DEV, generator=g) for _ in range(3))
+    dW, db, dg = torch.ones(Nn, K, device=DEV), torch.ones(Nn, device=DEV), torch.ones(Nn, device=DEV)
+    o.layerscale_wgrad(G, W, bias, cs, gamma, dW, db, dg, Nn, K)
+    assert torch.allclose(dW, 1 + gamma[:, None] * G, rtol=1e-5, atol=1e-5) and torch.allclose(db, 1 + gamma * cs, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(dg, 1 + (W * G).sum(1) + bias * cs, rtol=1e-4, atol=1e-3)
+    wt = torch.empty(K, Nn, dtype=torch.bfloat16, device=DEV)
+    o.scaled_transpose(W, gamma, wt, Nn, K)
+    assert torch.equal(wt, (W * gamma[:, None]).T.to(torch.bfloat16))
+
+
+def _model(init_values):
+    from oracle.ref_stubs import TINY
+    from vtp_amd import VTPConfig, VTPModel
+    cfg = dict(TINY)
+    cfg.update(vision_depth=3, decoder_depth=2, vision_init_values=init_values, decoder_init_values=init_values and 0.6 * init_values)
+    torch.manual_seed(8)
+    m = VTPModel(VTPConfig(**cfg))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim <= 1 and p.numel() > 1:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to(DEV), sd
+
+
+def _compare_grads(m, ref_sd, keys, tol, ref16=None):
+    """E_ours vs the fp32 oracle autograd; with `ref16` (the same oracle graph under bf16 autocast) the bound is the usual
+    max(1.5 E_ref, tol) of the parity protocol"""
+    params = dict(m.named_parameters())
+    for k in keys:
+        e = relF(params[k].grad, ref_sd[k].grad)
+        e_ref = relF(ref16[k].grad, ref_sd[k].grad) if ref16 is not None else 0.0
+        print(f"   grad {k}: E_ours {e:.3e} E_ref {e_ref:.3e}")
+        assert e <= max(1.5 * e_ref, tol), k
+
+
+def test_layerscale_forward_backward_vs_oracle():
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPTrainer
+    m, sd = _model(0.5)
+    assert "trunk.blocks.0.ls1.gamma" in sd and "pixel_decoder.blocks.1.ls2.gamma" in sd
+    img = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    m.eval()
+    lat = m.get_reconstruction_latents(img.to(DEV))
+    with torch.no_grad():
+        lat_ref = O.reconstruction_latents(sd, img, 2)
+    print(f"LayerScale latents rel {relF(lat, lat_ref):.3e}")
+    assert relF(lat, lat_ref) < 1.5e-2
+    m.train()
+    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    loss_ref = O.rec_train_loss(ref, img, 2, 2)
+    loss_ref.backward()
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0)
+    loss = tr.step_rec(img.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+    _compare_grads(m, ref, ["trunk.blocks.0.ls1.gamma", "trunk.blocks.2.ls2.gamma", "pixel_decoder.blocks.0.ls1.gamma",
+                            "pixel_decoder.blocks.1.ls2.gamma", "trunk.blocks.1.attn.proj.weight", "trunk.blocks.1.attn.proj.bias",
+                            "trunk.blocks.0.mlp.w3.weight", "trunk.blocks.2.mlp.w3.bias", "trunk.blocks.0.attn.qkv.weight",
+                            "pixel_decoder.blocks.1.mlp.w3.bias", "pixel_decoder.blocks.0.mlp.w1.weight", "trunk.patch_embed.proj.weight"], 4e-2)
+
+
+@pytest.mark.parametrize("init_values", [None, 0.5])
+def test_stochastic_depth_step_vs_oracle(init_values):
+    """drop_rate 0.4 on 5 images (keep 3, alpha 5/3) in trunk AND decoder: loss and gradients of the rec step vs the oracle's
+    autograd evaluated with the SAME image subsets (read back from the trainer's drop plan)."""
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPTrainer
+    m, sd = _model(init_values)
+    B = 5
+    img = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=3)
+    loss = tr.step_rec(img.to(DEV))
+    torch.cuda.synchronize()
+
+    def plan_of(stack):
+        p = stack.drop_plan
+        keep, alpha = p["keeps"][0], p["scales"][0]
+        assert keep == 3 and abs(alpha - B / 3) < 1e-9
+        idx = p["idx_dev"].cpu().long().view(stack.depth, 2, keep)
+        return [(idx[i, 0], alpha, idx[i, 1], alpha) for i in range(stack.depth)]
+
+    d_tr, d_dec = plan_of(tr.trunk.stack), plan_of(tr.decoder.stack)
+    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    out = O.trunk_forward(ref, img, 2, use_bottleneck=True, drop=d_tr)
+    lat = out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4)
+    loss_ref = O.l1_loss(O.decoder_forward(ref, lat, 2, drop=d_dec), img)
+    loss_ref.backward()
+    ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o16 = O.trunk_forward(ref16, img, 2, use_bottleneck=True, drop=d_tr)
+        l16 = O.l1_loss(O.decoder_forward(ref16, o16["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, drop=d_dec), img)
+    l16.backward()
+    print(f"stochastic depth (LayerScale {init_values}): loss ours {float(loss):.5f} oracle {float(loss_ref):.5f}")
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+    keys = ["trunk.blocks.0.attn.qkv.weight", "trunk.blocks.1.attn.proj.bias", "trunk.blocks.2.mlp.w3.weight", "trunk.blocks.1.mlp.w1.bias",
+            "trunk.blocks.0.norm1.weight", "trunk.blocks.2.norm2.weight", "trunk.patch_embed.proj.weight", "trunk.cls_token",
+            "pixel_decoder.blocks.0.attn.qkv.bias", "pixel_decoder.blocks.1.mlp.w3.bias", "pixel_decoder.blocks.1.norm2.bias",
+            "pixel_decoder.proj_in.weight"]
+    if init_values:
+        keys += ["trunk.blocks.1.ls1.gamma", "pixel_decoder.blocks.0.ls2.gamma"]
+    _compare_grads(m, ref, keys, 3e-2, ref16)
+    # a second step draws new subsets (same shapes: static index buffer refreshed in place) and the graph path agrees with eager
+    i0 = tr.trunk.stack.drop_plan["idx_dev"].clone()
+    tr.step_rec(img.to(DEV))
+    assert not torch.equal(i0, tr.trunk.stack.drop_plan["idx_dev"])
+    res = []
+    for use_graphs in (False, True):
+        m2, _ = _model(init_values)
+        t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=9, use_graphs=use_graphs)
+        res.append([float(t2.step_rec(img.to(DEV) + 0.01 * i)) for i in range(3)])
+    print("drop eager:", res[0], "graphs:", res[1])
+    for a, b in zip(*res):
+        assert abs(a - b) < 2e-3 * abs(a)

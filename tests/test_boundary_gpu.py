@@ -245,3 +245,29 @@ def test_legacy_ssl_forward_is_differentiable(legacy):
         e = relF(params[k].grad, ref[k].grad)
         print(f"   ssl grad {k}: {e:.3e}")
         assert e < 5e-2, k
+
+
+def test_torch_ops_vtp_hip_callable():
+    """the raw kernels through torch.ops.vtp_hip (torch.library registration, vtp_amd/torch_ops.py)"""
+    import vtp_amd.torch_ops  # noqa: F401
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, N, K = 300, 256, 128
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    torch.ops.vtp_hip.gemm_nt(a, w, c, bias, None, None, M, N, K, 0)
+    ref = a.float() @ w.float().T + bias
+    assert relF(c, ref) < 5e-3
+    x = torch.randn(M, N, device=DEV, generator=g)
+    wn = torch.rand(N, device=DEV, generator=g) + 0.5
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    st = torch.empty(M, 2, device=DEV)
+    torch.ops.vtp_hip.norm_fwd(x, wn, None, y, st, 1e-5, 0)
+    refn = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * wn
+    assert relF(y, refn) < 5e-3
+    dw = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    torch.ops.vtp_hip.gemm_tn(dy, a, dw, N, K, M, True, db)
+    assert relF(dw, dy.float().T @ a.float()) < 1e-3 and relF(db, dy.float().sum(0)) < 1e-3

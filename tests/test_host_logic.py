@@ -202,3 +202,30 @@ def test_block_mask_generator_and_ssl_collate():
     from vtp_amd.ssl_engine import build_ssl_indices
     p = build_ssl_indices(out["masks"].numpy(), B, 16, 4, 4, 1.0, 1.0, upperbound=out["upperbound"])
     assert p["Tm"] == max(64, (out["upperbound"] + 63) // 64 * 64) and p["n_masked"] == int(out["n_masked_patches"])
+
+
+def test_torch_library_registration():
+    """torch.ops.vtp_hip.* exist with schemas (CPU: registration + schema only; the GPU tests call them)."""
+    import torch
+    import vtp_amd.torch_ops as t
+    assert {"gemm_nt", "gemm_tn", "gemm_qkv_rope", "norm_fwd", "norm_bwd", "attn_fwd", "attn_bwd", "rope_qk", "adamw"} <= set(t.OPS)
+    for name in t.OPS:
+        op = getattr(torch.ops.vtp_hip, name)
+        assert "vtp_hip::" + name in str(op.default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):  # no CPU kernel: loud, never a silent fallback
+        torch.ops.vtp_hip.ema(torch.zeros(4), torch.zeros(4), 4, 0.5)
+
+
+def test_drop_allocation_matches_reference_rule():
+    """Stack.drop_allocation = get_branges_scales' allocation (block.py:27-33 single process, :44-62 under DDP)."""
+    from vtp_amd.engine import Stack
+    assert Stack.drop_allocation(5, 0.4) == (3, 5 / 3)
+    assert Stack.drop_allocation(4, 0.99) == (1, 4.0)
+    for b, r, W in ((32, 0.1, 8), (5, 0.4, 3), (7, 0.5, 4), (2, 0.9, 8)):
+        gb = b * W
+        gkeep = max(int(gb * (1 - r)), W)
+        base, extra = gkeep // W, gkeep % W
+        alloc = [min(base + (1 if i < extra else 0), b) for i in range(W)]
+        for rank in range(W):
+            k, sc = Stack.drop_allocation(b, r, W, rank)
+            assert k == alloc[rank] and abs(sc - gb / sum(alloc)) < 1e-12

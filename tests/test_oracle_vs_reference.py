@@ -85,3 +85,43 @@ def test_intermediate_layers(ref_model):
                     torch.testing.assert_close(g_[1], r[1], rtol=2e-4, atol=2e-5)
                 else:
                     torch.testing.assert_close(g_, r, rtol=2e-4, atol=2e-5)
+
+
+def test_layerscale_and_stochastic_depth_branch():
+    """LayerScale (vision_init_values) and the training branch with sample drop (block.py:207-233) of the REAL trunk vs the
+    oracle fed with the image subsets the reference drew (torch.randperm, replayed from the same seed in call order)."""
+    ns = load_reference()
+    torch.manual_seed(5)
+    cfg = dict(TINY)
+    cfg.update(image_size=64, vision_depth=3, vision_init_values=0.3, decoder_init_values=0.2)
+    m = ns.VTPModel(ns.VTPConfig(**cfg))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim <= 1 and p.numel() > 1:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = m.state_dict()
+    assert "trunk.blocks.0.ls1.gamma" in sd and "pixel_decoder.blocks.1.ls2.gamma" in sd
+    img = torch.randn(5, 3, 64, 64)
+    m.eval()
+    with torch.no_grad():
+        lat_ref = m.get_reconstruction_latents(img)
+        rec_ref = m.get_latents_decoded_images(lat_ref)
+        torch.testing.assert_close(O.reconstruction_latents(sd, img, 2), lat_ref, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(O.decoder_forward(sd, lat_ref, 2), rec_ref, rtol=2e-4, atol=2e-5)
+    # training branch: drop_ratio 0.4 on 5 images -> keep 3, alpha 5/3
+    m.train()
+    ratio, B = 0.4, 5
+    torch.manual_seed(11)
+    with torch.no_grad():
+        r = m.trunk(img, is_training=True, use_bottleneck=False, drop_ratio=ratio)
+    torch.manual_seed(11)
+    keep = max(int(B * (1 - ratio)), 1)
+    drop = []
+    for _ in range(3):
+        i1 = torch.randperm(B)[:keep]
+        i2 = torch.randperm(B)[:keep]
+        drop.append((i1, B / keep, i2, B / keep))
+    with torch.no_grad():
+        o = O.trunk_forward(sd, img, 2, use_bottleneck=False, drop=drop)
+    torch.testing.assert_close(o["x_norm_patchtokens"], r["x_norm_patchtokens"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(o["x_norm_clstoken"], r["x_norm_clstoken"], rtol=2e-4, atol=2e-5)

@@ -39,6 +39,10 @@ SIGNATURES = {
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_colsum_bf16_rows": [_P, _I, _P, _P, _I, _I, _P],
+    "vtp_gather_image_rows": [_P, _P, _P, _P, _I, _L, _I, _F, _P],
+    "vtp_scatter_image_rows": [_P, _P, _P, _I, _L, _I, _F, _I, _P],
+    "vtp_layerscale_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vtp_scaled_transpose": [_P, _P, _P, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_ema": [_P, _P, _L, _F, _P],
     "vtp_gather_token_rows": [_P, _P, _P, _I, _I, _P],

@@ -82,6 +82,7 @@ class VTPConfig:
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
         need(not self.text_quick_gelu, "quick_gelu is not implemented")
         need(self.init_logit_bias is None, "SigLIP logit_bias is not implemented")
+        need(self.text_ls_init_value is None, "LayerScale in the text tower (text_ls_init_value) is not implemented")
 
     def to_dict(self):
         d = {k: v for k, v in self.__dict__.items() if k != "extra"}

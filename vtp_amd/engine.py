@@ -29,8 +29,9 @@ from .ops import EPI_BF16, EPI_F32, EPI_F32_ATOMIC, EPI_F32_SLAB, EPI_GELU, EPI_
 # parameters: flat fp32 masters + flat fp32 grads + bf16 compute copies refreshed by ONE batched kernel
 # =====================================================================================================================
 class Lin:
-    """Compute-side record of one linear map y = x W^T + b  (W fp32 master [N,K])."""
-    __slots__ = ("N", "K", "w", "wT", "bias", "gw", "gb")
+    """Compute-side record of one linear map y = x W^T + b  (W fp32 master [N,K]).  w32: the fp32 master as [N,K]; wTs: bf16
+    (gamma (.) W)^T, the dgrad operand when a LayerScale follows the linear (refreshed by a prep hook)."""
+    __slots__ = ("N", "K", "w", "wT", "bias", "gw", "gb", "w32", "wTs")
 
 
 class SwiGLULin:
@@ -111,6 +112,7 @@ class ParamStore:
         L.gw = self.g(wname)
         L.gb = self.g(bname) if bname and self.has(bname) else None
         L.wT = None
+        L.w32, L.wTs = self.p(wname).view(N, K), None
         self._want_bf16(L, "w", N * K, (N, K))
         if need_T:
             self._want_bf16(L, "wT", N * K, (K, N))
@@ -280,7 +282,7 @@ def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
                x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0,
-               bias_grad_done: bool = False):
+               bias_grad_done: bool = False, ls=None):
     """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
     column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
@@ -291,6 +293,32 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         gw = L.gw if gw is None else gw
         gb = L.gb if gb is None else gb
         wT = L.wT if wT is None else wT
+    if ls is not None:
+        # y = gamma (.) (x W^T + b) (LayerScale, misc.py:24-25) and dy_b is the gradient of y: the branch output f is not stored
+        # -- G = dy^T x and cs = colsum(dy) give dW = gamma (.) G, db = gamma (.) cs, dgamma = rowsum(W (.) G) + b (.) cs
+        gamma, g_gamma = ls
+        assert WGRAD_TN and L is not None and not swiglu_h and dy_remap == (0, 0) and x_remap == (0, 0)
+        cs = ws.get("T.ls_cs", (N,), F32)
+        cs.zero_()
+        G = ws.get("T.ls_G", (N * K,), F32)
+
+        def wgrad_ls():
+            kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_colsum=cs)
+            St = ops.gemm_tn_splits(N, K, M)
+            if St == 1:
+                ops.gemm_tn(dy_b, x_b, G, epi=EPI_F32, **kw)
+            else:
+                slab = ws.get("T.slab", (St * N * K,), F32)
+                ops.gemm_tn(dy_b, x_b, slab, ldc2=N * K // 4, epi=EPI_F32_SLAB, splits=St, **kw)
+                ops.reduce_slabs(slab, N * K, St, G, N * K, accumulate=False)
+            ops.layerscale_wgrad(G, L.w32, L.bias, cs, gamma, gw, gb, g_gamma, N, K)
+
+        OVERLAP.join()
+        wgrad_ls()
+        if need_dx:
+            ops.gemm_nt(dy_b, L.wTs, d_in, M=M, N=K, K=N, lda=dy_b.stride(0), ldb=N, ldc=d_in.stride(0), epi=EPI_BF16,
+                        c_remap=dx_remap)
+        return
     if bias_grad_done:  # the kernel that produced dy_b already accumulated its column sums into the bias gradient
         gb = None
     Mp = pad8(M)
@@ -394,7 +422,16 @@ class Stack:
                 b.w3 = store.lin(pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", D, H)
             b.ls1 = store.p(pre + "ls1.gamma") if store.has(pre + "ls1.gamma") else None
             b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
+            b.gls1 = store.g(pre + "ls1.gamma") if b.ls1 is not None else None
+            b.gls2 = store.g(pre + "ls2.gamma") if b.ls2 is not None else None
+            for L, gam in ((b.proj, b.ls1), (b.w3, b.ls2)):
+                if gam is not None:  # dgrad operand (gamma (.) W)^T, refreshed with the other bf16 copies
+                    L.wTs = torch.empty(L.K, L.N, dtype=BF, device=store.device)
+                    if not hasattr(store, "prep_hooks"):
+                        store.prep_hooks = []
+                    store.prep_hooks.append(lambda L=L, gam=gam: ops.scaled_transpose(L.w32, gam, L.wTs, L.N, L.K))
             self.blocks.append(b)
+        self.drop_plan = None  # stochastic depth (set per step by set_drop_plan)
 
     def _rope_plan(self, ws: Workspace, segs, prefix_tokens: int, M: int):
         """(rope_pos int32 [M], sin, cos) for the fused qkv + RoPE epilogue: rope_pos[m] = row of the concatenated per-segment
@@ -422,6 +459,168 @@ class Stack:
         assert plan[0].numel() == M
         ws._rope_plan = (key, plan)
         return plan
+
+    # ------------------------------------------------------------------------------------------------ stochastic depth
+    # block.py:20-118 (get_branges_scales) and :207-289: in training with drop_ratio > 0 every residual branch of every block runs
+    # on a fresh random subset of the images of each list item and is added back with alpha = batch / kept.
+    @staticmethod
+    def drop_allocation(b: int, ratio: float, world: int = 1, rank: int = 0):
+        """(images kept on this rank, residual scale factor) -- the reference's allocation rule: without DDP keep =
+        max(int(b (1 - r)), 1), scale = b / keep; with DDP the GLOBAL keep count max(int(b W (1 - r)), W) is spread evenly over the
+        ranks and scale = global batch / global kept (block.py:44-62; deterministic, so no broadcast is needed here)."""
+        if world <= 1:
+            keep = max(int(b * (1 - ratio)), 1)
+            return keep, b / keep
+        gb = b * world
+        gkeep = max(int(gb * (1 - ratio)), world)
+        base, extra = gkeep // world, gkeep % world
+        alloc = [min(base + (1 if i < extra else 0), b) for i in range(world)]
+        return alloc[rank], gb / max(sum(alloc), 1)
+
+    def make_drop_plan(self, segs, ratio: float, generator: Optional[torch.Generator] = None, world: int = 1, rank: int = 0):
+        """Host side, once per step: a random image subset per (block, branch, list item).  Returns a dict with the int32 index
+        tensor (CPU; copy it into the static device buffer with set_drop_plan) and the static shape information."""
+        keeps, scales = [], []
+        for B, _, _ in segs:
+            k, sc = self.drop_allocation(B, ratio, world, rank)
+            keeps.append(k)
+            scales.append(sc)
+        per = sum(keeps)
+        idx = torch.empty(self.depth * 2 * per, dtype=torch.int32)
+        o = 0
+        for _ in range(self.depth * 2):
+            for (B, _, _), k in zip(segs, keeps):
+                idx[o:o + k] = torch.randperm(B, generator=generator)[:k].to(torch.int32)
+                o += k
+        return dict(idx=idx, keeps=keeps, scales=scales, per=per, ratio=ratio)
+
+    def set_drop_plan(self, plan, ws_key="drop"):
+        """activate / update (plan) or switch off (None) stochastic depth for the following forward + backward"""
+        if plan is None:
+            self.drop_plan = None
+            return
+        dev = self.store.device
+        cur = self.drop_plan
+        if cur is None or cur["idx_dev"].numel() != plan["idx"].numel():
+            cur = dict(plan)
+            cur["idx_dev"] = plan["idx"].to(dev)
+        else:  # same shapes: refresh the static index buffer in place (graph replay reads it)
+            cur["idx_dev"].copy_(plan["idx"], non_blocking=True)
+            cur.update(keeps=plan["keeps"], scales=plan["scales"], per=plan["per"], ratio=plan["ratio"])
+        self.drop_plan = cur
+
+    def _drop_idx(self, i: int, branch: int, s: int):
+        p = self.drop_plan
+        o = (i * 2 + branch) * p["per"] + sum(p["keeps"][:s])
+        return p["idx_dev"][o:o + p["keeps"][s]]
+
+    def forward_drop(self, ws: Workspace, x, segs, prefix_tokens: int):
+        """training forward with stochastic depth; `x` (f32 [M, D]) is updated IN PLACE block after block (the branch inputs that
+        backward needs are the gathered compact copies).  segs = [(B_i, N_i, rope_i)]."""
+        D, H, heads = self.D, self.H, self.heads
+        p = self.drop_plan
+        keeps, scales = p["keeps"], p["scales"]
+        csegs = [(k, N, rp) for (B, N, rp), k in zip(segs, keeps)]  # the compact (gathered) list
+        Mc = sum(k * N for k, N, _ in csegs)
+        scale = 1.0 / math.sqrt(64.0)
+        rope_plan = self._rope_plan(ws, csegs, prefix_tokens, Mc) if FUSE_ROPE else None
+        saved_all = []
+        for i, b in enumerate(self.blocks):
+            t = f"{i}.d."
+            xs1, xs2 = ws.get(t + "xs1", (Mc, D), F32), ws.get(t + "xs2", (Mc, D), F32)
+            xn1, st1 = ws.get(t + "xn1", (Mc, D), BF), ws.get(t + "st1", (Mc, 2), F32)
+            qkv, o = ws.get(t + "qkv", (Mc, 3 * D), BF), ws.get(t + "o", (Mc, D), BF)
+            lse = ws.get(t + "lse", (Mc * heads,), F32)
+            xn2, st2 = ws.get(t + "xn2", (Mc, D), BF), ws.get(t + "st2", (Mc, 2), F32)
+            pre, hid = ws.get(t + "x12", (Mc, 2 * H), BF), ws.get(t + "hid", (Mc, H), BF)
+            delta = ws.get("d.delta", (Mc, D), F32)
+            # ---- attention branch on the kept images
+            self._gather(x, segs, csegs, i, 0, xs1, None, 1.0)
+            ops.norm_fwd(xs1, b.n1w, b.n1b, xn1, st1, Mc, D, self.eps, self.kind)
+            if rope_plan is not None:
+                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, Mc, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+            else:
+                ops.gemm_nt(xn1, b.qkv.w, qkv, M=Mc, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
+            for r0, Bs, Ns, rp in self._rows(csegs):
+                q_s = qkv[r0:r0 + Bs * Ns]
+                if rp is not None and rope_plan is None:
+                    ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
+                ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r0 + Bs * Ns], lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D,
+                             Ns * D, D, scale, self.causal)
+            ops.gemm_nt(o, b.proj.w, delta, M=Mc, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, epi=EPI_F32)
+            self._scatter(delta, x, segs, csegs, i, 0, scales, accumulate=True)  # x_attn = index_add(x, residual, alpha)
+            # ---- FFN branch on an independent subset
+            self._gather(x, segs, csegs, i, 1, xs2, None, 1.0)
+            ops.norm_fwd(xs2, b.n2w, b.n2b, xn2, st2, Mc, D, self.eps, self.kind)
+            ops.gemm_nt(xn2, b.w12.w12, hid, M=Mc, N=2 * H, K=D, c2=pre, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            ops.gemm_nt(hid, b.w3.w, delta, M=Mc, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, epi=EPI_F32)
+            self._scatter(delta, x, segs, csegs, i, 1, scales, accumulate=True)
+            saved_all.append((xs1, xn1, st1, qkv, o, lse, xs2, xn2, st2, pre, hid))
+        self.last_saved = saved_all
+        return x
+
+    def _gather(self, x, segs, csegs, i, branch, dst, dst_b, scale_by_seg):
+        D = self.D
+        r_full, r_c = 0, 0
+        for s, ((B, N, _), (k, _, _)) in enumerate(zip(segs, csegs)):
+            sc = scale_by_seg[s] if isinstance(scale_by_seg, (list, tuple)) else scale_by_seg
+            ops.gather_image_rows(x[r_full:], self._drop_idx(i, branch, s), None if dst is None else dst[r_c:],
+                                  None if dst_b is None else dst_b[r_c:], k, N, D, sc)
+            r_full += B * N
+            r_c += k * N
+
+    def _scatter(self, src, x, segs, csegs, i, branch, alpha_by_seg, accumulate):
+        D = self.D
+        r_full, r_c = 0, 0
+        for s, ((B, N, _), (k, _, _)) in enumerate(zip(segs, csegs)):
+            al = alpha_by_seg[s] if isinstance(alpha_by_seg, (list, tuple)) else alpha_by_seg
+            ops.scatter_image_rows(src[r_c:], self._drop_idx(i, branch, s), x[r_full:], k, N, D, al, accumulate)
+            r_full += B * N
+            r_c += k * N
+
+    def backward_drop(self, ws: Workspace, dy, segs, prefix_tokens: int, saved):
+        """backward of forward_drop; `dy` (f32 [M, D], gradient of the stack output) is updated IN PLACE into the gradient of the
+        stack input.  Generator (see backward)."""
+        D, H, heads = self.D, self.H, self.heads
+        p = self.drop_plan
+        keeps, scales = p["keeps"], p["scales"]
+        csegs = [(k, N, rp) for (B, N, rp), k in zip(segs, keeps)]
+        Mc = sum(k * N for k, N, _ in csegs)
+        scale = 1.0 / math.sqrt(64.0)
+        dh = ws.get("b.d.dh", (Mc, H), BF)
+        dpre = ws.get("b.d.dx12", (Mc, 2 * H), BF)
+        dxn = ws.get("b.d.dxn", (Mc, D), BF)
+        d_o = ws.get("b.d.do", (Mc, D), BF)
+        dqkv = ws.get("b.d.dqkv", (Mc, 3 * D), BF)
+        delta = ws.get("b.d.delta", (Mc * heads,), F32)
+        gdy_b = ws.get("b.d.gdy_b", (Mc, D), BF)
+        gdy = ws.get("b.d.gdy", (Mc, D), F32)
+        dxc = ws.get("b.d.dxc", (Mc, D), F32)
+        for i in range(self.depth - 1, -1, -1):
+            b = self.blocks[i]
+            xs1, xn1, st1, qkv, o, lse, xs2, xn2, st2, pre, hid = saved[i]
+            # ---- FFN branch: d(delta2) = alpha * dy[kept rows]; the branch-input gradient lands on the same rows
+            self._gather(dy, segs, csegs, i, 1, gdy, gdy_b, scales)
+            linear_bwd(ws, "w3", b.w3, gdy_b, hid, Mc, dh, ls=(b.ls2, b.gls2) if b.ls2 is not None else None)
+            ops.swiglu_bwd(dh, pre, dpre, Mc, H)
+            linear_bwd(ws, "w12", None, dpre, xn2, Mc, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T, swiglu_h=H)
+            ops.norm_bwd(dxn, xs2, b.n2w, st2, gdy, dxc, None, b.gn2w, b.gn2b, Mc, D, self.kind)   # dxc = dy[kept] + norm bwd
+            self._scatter(dxc, dy, segs, csegs, i, 1, 1.0, accumulate=False)
+            # ---- attention branch
+            self._gather(dy, segs, csegs, i, 0, gdy, gdy_b, scales)
+            linear_bwd(ws, "proj", b.proj, gdy_b, o, Mc, d_o, ls=(b.ls1, b.gls1) if b.ls1 is not None else None)
+            for r0, Bs, Ns, rp in self._rows(csegs):
+                r1 = r0 + Bs * Ns
+                q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
+                ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
+                             dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
+                             rope=rp, rope_prefix=prefix_tokens)
+            linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, Mc, dxn)
+            ops.norm_bwd(dxn, xs1, b.n1w, st1, gdy, dxc, None, b.gn1w, b.gn1b, Mc, D, self.kind)
+            self._scatter(dxc, dy, segs, csegs, i, 0, 1.0, accumulate=False)
+            OVERLAP.join()
+            yield ("block", i)
+        return dy
 
     @staticmethod
     def _rows(segs):
@@ -482,6 +681,13 @@ class Stack:
         self.last_saved = saved_all  # per-call context: several forward passes may be in flight before their backward
         return x
 
+    def w3_colsum_target(self, i: int):
+        """where the norm backward in front of block i's w3 gradient may add the column sums of its bf16 output (= w3's bias
+        gradient); None when a LayerScale sits between them (the bias gradient then needs the gamma factor) or under
+        stochastic depth (the FFN branch sees a gathered subset of the rows)"""
+        b = self.blocks[i]
+        return b.w3.gb if (b.ls2 is None and self.drop_plan is None) else None
+
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
     def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None, segs=None,
                  dy_colsum_done: bool = False):
@@ -505,12 +711,13 @@ class Stack:
         saved = self.last_saved if saved is None else saved
         for i in range(self.depth - 1, -1, -1):
             b = self.blocks[i]
-            assert b.ls1 is None and b.ls2 is None, "LayerScale backward is not implemented"
             x_in, xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid = saved[i]
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
             # ---- FFN: x_out = x_mid + w3(act(...))
-            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh, bias_grad_done=dy_colsum_done or i < self.depth - 1)
+            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh,
+                       bias_grad_done=dy_colsum_done if i == self.depth - 1 else self.w3_colsum_target(i) is not None,
+                       ls=(b.ls2, b.gls2) if b.ls2 is not None else None)
             if vit:
                 # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
                 # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
@@ -523,9 +730,11 @@ class Stack:
                 linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn)
             # the norm backward kernels also sum the columns of their bf16 output = the bias gradient of the linear layer that
             # takes it as dy (proj here; the previous block's w3 below)
-            ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind, dx_colsum=b.proj.gb)
+            ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind,
+                         dx_colsum=b.proj.gb if b.ls1 is None else None)
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
-            linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o, bias_grad_done=b.proj.gb is not None)
+            linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o, bias_grad_done=b.proj.gb is not None,
+                       ls=(b.ls1, b.gls1) if b.ls1 is not None else None)
             for r0, Bs, Ns, rp in self._rows(segs):
                 r1 = r0 + Bs * Ns
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
@@ -535,7 +744,7 @@ class Stack:
                              rope=rp, rope_prefix=prefix_tokens)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
             ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind,
-                         dx_colsum=self.blocks[i - 1].w3.gb if i > 0 else None)
+                         dx_colsum=self.w3_colsum_target(i - 1) if i > 0 else None)
             dy, dy_b = dxo, dxo_b
             OVERLAP.join()
             yield ("block", i)
@@ -626,7 +835,11 @@ class TrunkEngine:
             ops.gemm_nt(pt, self.pe.w, xs, M=g.B * g.hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(g.hw, 1))
             ops.assemble_tokens(xs, st.p(self.prefix + "cls_token"), st.p(self.prefix + "mask_token"), g.masks, g.B, g.N, D)
         stack_segs = [(g.B, g.N, g.rope) for g in segs]
-        xl = self.stack.forward(ws, x0, 0, 0, None, 1, train, segs=stack_segs)
+        dropped = train and self.stack.drop_plan is not None
+        if dropped:  # stochastic depth (block.py:207-289): residual branches on random image subsets, x0 updated in place
+            xl = self.stack.forward_drop(ws, x0, stack_segs, 1)
+        else:
+            xl = self.stack.forward(ws, x0, 0, 0, None, 1, train, segs=stack_segs)
         xnf = ws.get("xnf", (M, D), BF)
         stf = ws.get("stf", (M, 2), F32)
         ops.norm_fwd(xl, st.p(self.prefix + "norm.weight"), st.p(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, xnf, stf,
@@ -634,6 +847,7 @@ class TrunkEngine:
         c = TrunkCtx()
         c.ws, c.segs, c.M, c.xl, c.xnf, c.stf, c.patches, c.stack_saved, c.x0, c.stack_segs = \
             ws, segs, M, xl, xnf, stf, patches, self.stack.last_saved, x0, stack_segs
+        c.dropped = dropped
         self._ctx = c
         return xnf
 
@@ -673,11 +887,16 @@ class TrunkEngine:
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, c.xl, st.p(self.prefix + "norm.weight"), c.stf, None, dx, dx_b, st.g(self.prefix + "norm.weight"),
                      st.g(self.prefix + "norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind,
-                     dx_colsum=self.stack.blocks[-1].w3.gb)
+                     dx_colsum=self.stack.w3_colsum_target(self.depth - 1))
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs,
-                                                    dy_colsum_done=True)
+        if getattr(c, "dropped", False):
+            dx0 = yield from self.stack.backward_drop(ws, dx, c.stack_segs, 1, c.stack_saved)
+            dx0_b = dx_b
+            ops.cast_f32_bf16(dx0, dx0_b, M * D)
+        else:
+            dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs,
+                                                        dy_colsum_done=self.stack.w3_colsum_target(self.depth - 1) is not None)
         for g in c.segs:
             d_s, d_sb = dx0[g.row0:g.row0 + g.B * g.N], dx0_b[g.row0:g.row0 + g.B * g.N]
             if g.masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
@@ -729,7 +948,11 @@ class DecoderEngine:
         x0 = ws.get("x0", (M, D), F32)
         ops.gemm_nt(lat, self.pin.w, x0, M=M, N=D, K=self.cin, bias=self.pin.bias, epi=EPI_F32)
         rope = rope_tables(self.periods, h, w, st.device)
-        xl = self.stack.forward(ws, x0, B, h * w, rope, 0, train)
+        dropped = train and self.stack.drop_plan is not None
+        if dropped:
+            xl = self.stack.forward_drop(ws, x0, [(B, h * w, rope)], 0)
+        else:
+            xl = self.stack.forward(ws, x0, B, h * w, rope, 0, train)
         xnf = ws.get("xnf", (M, D), BF)
         stf = ws.get("stf", (M, 2), F32)
         ops.norm_fwd(xl, st.p("pixel_decoder.norm.weight"),
@@ -737,6 +960,7 @@ class DecoderEngine:
         t = ws.get("t", (M, 768), BF)
         ops.gemm_nt(xnf, self.pout.w, t, M=M, N=768, K=D, bias=self.pout.bias, epi=EPI_BF16)
         self._ctx = (ws, B, h, w, lat, xl, xnf, stf, rope, self.stack.last_saved)
+        self._dropped = dropped
         return t
 
     def backward(self, dt: torch.Tensor):
@@ -751,10 +975,16 @@ class DecoderEngine:
         dx_b = ws.get("b.dxt_b", (M, D), BF)
         ops.norm_bwd(d_xnf, xl, st.p("pixel_decoder.norm.weight"), stf, None, dx, dx_b, st.g("pixel_decoder.norm.weight"),
                      st.g("pixel_decoder.norm.bias") if self.kind == ops.NORM_LN else None, M, D, self.kind,
-                     dx_colsum=self.stack.blocks[-1].w3.gb)
+                     dx_colsum=self.stack.w3_colsum_target(self.depth - 1))
         OVERLAP.join()
         yield "tail"
-        dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, stack_saved, dy_colsum_done=True)
+        if getattr(self, "_dropped", False):
+            dx0 = yield from self.stack.backward_drop(ws, dx, [(B, h * w, rope)], 0, stack_saved)
+            dx0_b = dx_b
+            ops.cast_f32_bf16(dx0, dx0_b, M * D)
+        else:
+            dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, B, h * w, rope, 0, stack_saved,
+                                                        dy_colsum_done=self.stack.w3_colsum_target(self.depth - 1) is not None)
         d_lat = ws.get("b.d_lat", (M, self.cin), BF)
         linear_bwd(ws, "pin", self.pin, dx0_b, lat, M, d_lat)
         OVERLAP.join()

@@ -44,18 +44,26 @@ def _norm(dim: int, bias: bool) -> nn.Module:
     return m
 
 
-def _vit_block(D: int, H: int, norm: str) -> nn.Module:
-    """Parameter tree of SelfAttentionBlock (block.py:159-187)."""
+def _vit_block(D: int, H: int, norm: str, init_values=None) -> nn.Module:
+    """Parameter tree of SelfAttentionBlock (block.py:159-187); ls1 / ls2 = LayerScale gammas (misc.py:7-26) when `init_values`."""
     b = _holder()
     b.norm1 = _norm(D, norm != "rmsnorm")
     b.attn = _holder()
     b.attn.qkv = _linear(3 * D, D)
     b.attn.proj = _linear(D, D)
+    if init_values:
+        b.ls1 = _holder()
+        b.ls1.gamma = _param(D)
+        b.ls1.init_values = float(init_values)
     b.norm2 = _norm(D, norm != "rmsnorm")
     b.mlp = _holder()
     b.mlp.w1 = _linear(H, D)
     b.mlp.w2 = _linear(H, D)
     b.mlp.w3 = _linear(D, H)
+    if init_values:
+        b.ls2 = _holder()
+        b.ls2.gamma = _param(D)
+        b.ls2.init_values = float(init_values)
     return b
 
 
@@ -84,7 +92,7 @@ class VTPModel(nn.Module):
         t.rope_embed = _holder()
         t.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
         Hv = swiglu_hidden(D, c.vision_mlp_ratio)
-        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer) for _ in range(c.vision_depth)])
+        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer, c.vision_init_values) for _ in range(c.vision_depth)])
         t.norm = _norm(D, c.vision_norm_layer != "rmsnorm")
         if c.vision_feature_bottleneck is not None and c.vision_feature_bottleneck != D:
             t.feature_bottleneck = _holder()
@@ -105,7 +113,7 @@ class VTPModel(nn.Module):
             d.rope_embed = _holder()
             d.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
             Hd = swiglu_hidden(Dd, 4.0)
-            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer) for _ in range(c.decoder_depth)])
+            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer, c.decoder_init_values) for _ in range(c.decoder_depth)])
             d.norm = _norm(Dd, c.decoder_norm_layer != "rmsnorm")
             d.proj_out = _holder()
             d.proj_out.weight = _param(768, Dd, 1, 1)
@@ -154,6 +162,8 @@ class VTPModel(nn.Module):
             for name, p in prefix_mod.named_parameters():
                 if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
                     p.fill_(1.0)
+                elif name.endswith(".gamma"):  # LayerScale.reset_parameters (misc.py:21-22)
+                    p.fill_(c.vision_init_values if prefix_mod is self.trunk else c.decoder_init_values)
                 elif name.endswith(".bias"):
                     p.zero_()
                 elif name.endswith(".weight") and p.ndim == 2:

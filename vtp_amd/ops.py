@@ -154,6 +154,24 @@ def colsum_bf16_rows(inp, ld, out, n_rows_dev, R_max, C):
     _lib.check(_lib_().vtp_colsum_bf16_rows(_p(inp), ld, _p(out), _p(n_rows_dev), R_max, C, _s()), "vtp_colsum_bf16_rows")
 
 
+def gather_image_rows(src, idx, dst, dst_bf16, n_img, N, D, scale=1.0):
+    _lib.check(_lib_().vtp_gather_image_rows(_p(src), _p(idx), _p(dst), _p(dst_bf16), n_img, N, D, scale, _s()), "vtp_gather_image_rows")
+
+
+def scatter_image_rows(src, idx, dst, n_img, N, D, alpha=1.0, accumulate=True):
+    _lib.check(_lib_().vtp_scatter_image_rows(_p(src), _p(idx), _p(dst), n_img, N, D, alpha, int(accumulate), _s()),
+               "vtp_scatter_image_rows")
+
+
+def layerscale_wgrad(G, W, bias, colsum, gamma, dW, db, dgamma, N, K):
+    _lib.check(_lib_().vtp_layerscale_wgrad(_p(G), _p(W), _p(bias), _p(colsum), _p(gamma), _p(dW), _p(db), _p(dgamma), N, K, _s()),
+               "vtp_layerscale_wgrad")
+
+
+def scaled_transpose(W, gamma, dstT, N, K):
+    _lib.check(_lib_().vtp_scaled_transpose(_p(W), _p(gamma), _p(dstT), N, K, _s()), "vtp_scaled_transpose")
+
+
 def gemm_splits(K, splits):
     return _lib_().vtp_gemm_splits(K, splits)
 

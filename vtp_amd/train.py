@@ -93,10 +93,16 @@ class VTPTrainer:
                  group=None, bucket_blocks: int = 3, use_graphs: bool = False, clip_weight: float = 1.0,
                  rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
-                 lpips=None, perceptual_weight: float = 0.0):
+                 lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
+                 drop_seed: int = 0):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
+        # stochastic depth (block.py:207-289): the student trunk's rate (the reference has one per objective -- clip_drop_rate,
+        # ssl_drop_rate, rec_drop_rate, vtp.py:205-207; the objectives share one trunk pass here, hence one rate and one draw per
+        # step) and the pixel decoder's drop_path_rate
+        self.drop_rate, self.decoder_drop_rate = float(drop_rate), float(decoder_drop_rate)
+        self._drop_gen = torch.Generator().manual_seed(int(drop_seed))
         self.lpips, self.perceptual_weight = lpips, float(perceptual_weight)
         if self.perceptual_weight > 0 and lpips is None:
             raise ValueError("perceptual_weight > 0 needs an LPIPS module")
@@ -475,6 +481,7 @@ class VTPTrainer:
             raise NotImplementedError(self._clip_unsupported)
         B, _, H, W = images.shape
         self._set_hyper()
+        self._draw_drop_plans(B, ssl)
         if self.use_graphs:
             self._step_graphs(images, text, ssl)
         else:
@@ -482,6 +489,16 @@ class VTPTrainer:
                 self._handle(ev)
         self.model._pver = self.model._param_version()
         return self.loss_sum / float(B * 3 * H * W), self.clip_loss_sum
+
+    def _draw_drop_plans(self, B: int, ssl):
+        """fresh image subsets for every block / branch of this step (host randperm -> static device index buffers)"""
+        for rate, eng, batches in ((self.drop_rate, self.trunk, [B] + ([ssl["global"].shape[0], ssl["local"].shape[0]] if ssl else [])),
+                                   (self.decoder_drop_rate, self.decoder, [B])):
+            if rate > 0:
+                plan = eng.stack.make_drop_plan([(b, 0, None) for b in batches], rate, self._drop_gen, self.world, self.rank)
+                eng.stack.set_drop_plan(plan)
+            else:
+                eng.stack.set_drop_plan(None)
 
     def step_rec(self, images: torch.Tensor) -> torch.Tensor:
         return self.step(images, None)[0]
@@ -519,7 +536,7 @@ class VTPTrainer:
         if ssl is not None:
             pl = ssl["plan"]
             skey = (tuple(ssl["global"].shape), tuple(ssl["local"].shape), pl["Ts"])  # Ts: padded (bucketed) row count
-        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey)
+        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate > 0, self.decoder_drop_rate > 0)
         plan = self._graphs.get(key)
         if plan is None:
             st = self.store
