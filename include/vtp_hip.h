@@ -212,6 +212,28 @@ int vtp_clip_loss(const float* img_local, const float* txt_local, const float* i
                   float* d_img_local, float* d_txt_local, float* d_img_all, float* d_txt_all, float* d_logit_scale,
                   float* scratch, void* stream);
 
+/* ---- loss-head variants the reference names but does not ship (parity unpinned, KATs = fp64 restatements) ----
+ * SigLIP (vtp.py:180,185-188 creates `logit_bias` when init_logit_bias is set; OpenCLIP SigLipLoss):
+ *   z = exp(logit_scale) <I_m, T_n> + logit_bias, y = +1 on matching pairs else -1, loss = weight * sum softplus(-y z).
+ *   vtp_clip_logits writes exp(ls) <A_m, B_n>; vtp_siglip_pairs turns them IN PLACE into G = dloss/dz and accumulates loss,
+ *   d log-scale and d bias; vtp_clip_grad_rows / _cols map G back to the feature gradients (local rows / gathered columns). */
+int vtp_clip_logits(const float* A, const float* B, const float* logit_scale, float* logits, int M, int N, int D, void* stream);
+int vtp_clip_grad_rows(const float* G, const float* B, const float* logit_scale, float* out, int M, int N, int D, int accumulate,
+                       void* stream);
+int vtp_clip_grad_cols(const float* G, const float* A, const float* logit_scale, float* out, int M, int N, int D, int accumulate,
+                       void* stream);
+int vtp_siglip_pairs(float* logits, const float* logit_bias, int B_local, int B_all, int label_offset, float weight,
+                     float* loss_sum, float* d_logit_scale, float* d_logit_bias, void* stream);
+/* KoLeo (DINOv2 KoLeoLoss) on L2-normalised rows xn [B, D]: loss += -weight * sum_i log(|xn_i - xn_nn(i) + 1e-8| + eps), nn(i) = the
+ * other row with the largest dot product; d_xn (ACCUMULATED) receives the gradient w.r.t. xn (both ends of every pair). */
+int vtp_koleo(const float* xn, int* nn_scratch, float* d_xn, float* loss_sum, int B, int D, float weight, float eps, void* stream);
+/* Sinkhorn-Knopp centring (DINOv2 sinkhorn_knopp_teacher): probs bf16 [T, K] from teacher logits bf16 [T, K] at temperature
+ * 1 / inv_temp, n_iters alternating normalisations over prototypes and samples (count = total samples; count_dev / n_rows_dev:
+ * the same from device memory for padded buffers).  u [T], v [K], scratch [8 + K + T] f32.  phase -1 = everything (one process);
+ * phases 0..3 expose the steps between which a data-parallel caller all-reduces scratch[0] (max), scratch[8..8+K) (sums). */
+int vtp_sinkhorn_knopp(const void* logits, float inv_temp, void* probs, float* u, float* v, float* scratch, int T, int K, float count,
+                       const float* count_dev, const int* n_rows_dev, int n_iters, int phase, void* stream);
+
 /* ---- self-supervised (DINO / iBOT) head (ssl.hip) -----------------------------------------------------------
  * Token buffers of VTP.get_teacher_forward_outputs / get_student_ssl_outputs (vtp.py:432-439,470-473):
  * dst bf16 [T, D] row t = src row idx[t] (idx[t] < 0: zero row); scatter is the backward (indices are unique). */

@@ -354,18 +354,26 @@ def ssl_outputs(sd, global_crops, local_crops, masks, vis_heads: int):
 
 
 def ssl_loss(t_out, s_out, masks, center_dino, center_ibot, n_local: int, student_temp: float = 0.1,
-             teacher_temp: float = 0.07, dino_weight: float = 1.0, ibot_weight: float = 1.0) -> Tensor:
+             teacher_temp: float = 0.07, dino_weight: float = 1.0, ibot_weight: float = 1.0,
+             centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3) -> Tensor:
     """OUR SSL loss spec (DINOv2 conventions; the reference ships none -> parity unpinned):
       teacher targets  p = softmax((z_t - center) / teacher_temp)            (separate centres for cls / patch tokens)
       DINO  = [ sum_{local crop j, view v} mean_b CE(s_loc[j,b], p[v,b]) + sum_v mean_b CE(s_glob[v,b], p[other(v),b]) ]
               / (n_g (n_g - 1) + n_local n_g)            with the teacher cls rows already view-swapped (vtp.py:425-426)
       iBOT  = (1 / B) sum_masked tokens CE(s_patch, p_patch) / n_masked_in_image
-    Returns dino_weight * DINO + ibot_weight * iBOT."""
+    Returns dino_weight * DINO + ibot_weight * iBOT.
+    Variants (DINOv2 ssl_meta_arch conventions): centering="sinkhorn_knopp" replaces the centred softmax by
+    loss_oracle.sinkhorn_knopp over the cls rows / the masked patch rows; koleo_weight adds
+    koleo_weight * sum_v KoLeo(student global cls tokens of view v)."""
+    from .loss_oracle import koleo_loss, sinkhorn_knopp
     tc = t_out["teacher_cls_tokens_after_head"].detach()
     tp = t_out["masked_teacher_patch_tokens_after_head"].detach()
     B2 = tc.shape[0]
     B = B2 // 2
-    p_cls = F.softmax((tc - center_dino) / teacher_temp, dim=-1)
+    if centering == "sinkhorn_knopp":
+        p_cls = sinkhorn_knopp(tc.float(), teacher_temp, sk_iterations).float()
+    else:
+        p_cls = F.softmax((tc - center_dino) / teacher_temp, dim=-1)
     lsm_g = F.log_softmax(s_out["student_global_cls_tokens_after_head"] / student_temp, dim=-1)
     lsm_l = F.log_softmax(s_out["student_local_cls_tokens_after_head"] / student_temp, dim=-1)
     terms = 2 * 1 + n_local * 2
@@ -376,13 +384,20 @@ def ssl_loss(t_out, s_out, masks, center_dino, center_ibot, n_local: int, studen
     dino = dino / terms
     ibot = torch.zeros(())
     if tp.shape[0] > 0:
-        p_pat = F.softmax((tp - center_ibot) / teacher_temp, dim=-1)
+        if centering == "sinkhorn_knopp":
+            p_pat = sinkhorn_knopp(tp.float(), teacher_temp, sk_iterations).float()
+        else:
+            p_pat = F.softmax((tp - center_ibot) / teacher_temp, dim=-1)
         lsm_p = F.log_softmax(s_out["student_global_masked_patch_tokens_after_head"] / student_temp, dim=-1)
         per_img = masks.sum(1).clamp(min=1)
         img_of = masks.nonzero()[:, 0]
         w = 1.0 / per_img[img_of].float()
         ibot = -((p_pat * lsm_p).sum(-1) * w).sum() / B
-    return dino_weight * dino + ibot_weight * ibot
+    total = dino_weight * dino + ibot_weight * ibot
+    if koleo_weight:
+        for x in s_out["student_global_cls_tokens"].float().chunk(2):
+            total = total + koleo_weight * koleo_loss(x)[0]
+    return total
 
 
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, b1: float, b2: float,

@@ -43,7 +43,7 @@ def build_vtp(sd):
     m = VTP(cfg, dino_out_dim=C["K"], dino_hidden_dim=C["hidden"], dino_bottleneck_dim=C["bott"])
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
-    assert all(not k.startswith(("trunk.", "dino_head.", "teacher_")) for k in missing), missing
+    assert all(not k.startswith(("trunk.", "dino_head.", "teacher_trunk.", "teacher_dino_head.")) for k in missing), missing
     return m.to(DEV)
 
 

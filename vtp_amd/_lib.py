@@ -65,6 +65,12 @@ SIGNATURES = {
     "vtp_scatter_rows": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_l2norm_fwd": [_P, _P, _P, _I, _I, _F, _P],
     "vtp_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "vtp_clip_logits": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_clip_grad_rows": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vtp_clip_grad_cols": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vtp_siglip_pairs": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
+    "vtp_koleo": [_P, _P, _P, _P, _I, _I, _F, _F, _P],
+    "vtp_sinkhorn_knopp": [_P, _F, _P, _P, _P, _P, _I, _I, _F, _P, _P, _I, _I, _P],
     "vtp_clip_loss": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 

@@ -81,7 +81,6 @@ class VTPConfig:
              "text tower: only the causal / argmax-pooled CLIP configuration is implemented")
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
         need(not self.text_quick_gelu, "quick_gelu is not implemented")
-        need(self.init_logit_bias is None, "SigLIP logit_bias is not implemented")
         need(self.text_ls_init_value is None, "LayerScale in the text tower (text_ls_init_value) is not implemented")
 
     def to_dict(self):

@@ -228,6 +228,29 @@ extern "C" int vtp_l2norm_bwd(const float* dy, const float* y, const float* inv_
   return check_launch("l2norm_bwd");
 }
 
+// building blocks of the pairwise contrastive losses, exported for the SigLIP variant (vtp_siglip_pairs in losses.hip):
+//   logits[m,n] = exp(logit_scale) <A[m,:], B[n,:]> ;  out[m,:] (+)= exp(ls) sum_n G[m,n] B[n,:] ;  out[n,:] (+)= exp(ls) sum_m G[m,n] A[m,:]
+extern "C" int vtp_clip_logits(const float* A, const float* Bm, const float* logit_scale, float* logits, int M, int N, int D,
+                               void* stream) {
+  VTP_REQUIRE(A && Bm && logit_scale && logits && M > 0 && N > 0 && D > 0 && D % 4 == 0 && (size_t)D * 4 <= 65536, "vtp_clip_logits: bad argument");
+  hipLaunchKernelGGL(clip_logits_kernel, dim3(M), dim3(256), D * 4, (hipStream_t)stream, A, Bm, logit_scale, logits, M, N, D);
+  return check_launch("clip_logits");
+}
+
+extern "C" int vtp_clip_grad_rows(const float* G, const float* Bm, const float* logit_scale, float* out, int M, int N, int D,
+                                  int accumulate, void* stream) {
+  VTP_REQUIRE(G && Bm && logit_scale && out && M > 0 && N > 0 && D > 0 && (size_t)N * 4 <= 65536, "vtp_clip_grad_rows: bad argument");
+  hipLaunchKernelGGL(clip_gb_kernel, dim3(M), dim3(256), N * 4, (hipStream_t)stream, G, Bm, logit_scale, out, M, N, D, accumulate);
+  return check_launch("clip_grad_rows");
+}
+
+extern "C" int vtp_clip_grad_cols(const float* G, const float* A, const float* logit_scale, float* out, int M, int N, int D,
+                                  int accumulate, void* stream) {
+  VTP_REQUIRE(G && A && logit_scale && out && M > 0 && N > 0 && D > 0 && (size_t)M * 4 <= 65536, "vtp_clip_grad_cols: bad argument");
+  hipLaunchKernelGGL(clip_gta_kernel, dim3(N), dim3(256), M * 4, (hipStream_t)stream, G, A, logit_scale, out, M, N, D, accumulate);
+  return check_launch("clip_grad_cols");
+}
+
 extern "C" int vtp_clip_loss(const float* img_local, const float* txt_local, const float* img_all, const float* txt_all,
                              const float* logit_scale, int B_local, int B_all, int D, int label_offset, float* loss_sum,
                              float* d_img_local, float* d_txt_local, float* d_img_all, float* d_txt_all,

@@ -147,7 +147,11 @@ class VTPModel(nn.Module):
             self.context_length, self.vocab_size = c.text_context_length, c.text_vocab_size
             lshape = [1] if c.nonscalar_logit_scale else []
             self.logit_scale = nn.Parameter(torch.ones(lshape) * (c.init_logit_scale or np.log(1 / 0.07)))
-        self.logit_bias = None
+        # SigLIP (modeling_vtp.py:177-180): a learnable logit bias next to the logit scale
+        if c.train_clip and c.init_logit_bias is not None:
+            self.logit_bias = nn.Parameter(torch.ones([1] if c.nonscalar_logit_scale else []) * c.init_logit_bias)
+        else:
+            self.logit_bias = None
         self.reset_parameters()
         self._store: Optional[ParamStore] = None
 

@@ -219,6 +219,27 @@ def clip_loss(img_l, txt_l, img_all, txt_all, logit_scale, Bl, Bg, D, label_offs
                                      _p(scratch), _s()), "vtp_clip_loss")
 
 
+def siglip_loss(img_l, txt_all, logit_scale, logit_bias, Bl, Bg, D, label_offset, loss_sum, d_img_l, d_txt_all, d_logit_scale,
+                d_logit_bias, scratch):
+    """SigLIP (pairwise sigmoid) loss of the local images against all (gathered) texts: loss, feature gradients (local image rows
+    / gathered text columns -- reduce-scatter the latter across ranks), d log-scale, d bias.  weight = 1 / B_local."""
+    L, s = _lib_(), _s()
+    _lib.check(L.vtp_clip_logits(_p(img_l), _p(txt_all), _p(logit_scale), _p(scratch), Bl, Bg, D, s), "vtp_clip_logits")
+    _lib.check(L.vtp_siglip_pairs(_p(scratch), _p(logit_bias), Bl, Bg, label_offset, 1.0 / Bl, _p(loss_sum), _p(d_logit_scale),
+                                  _p(d_logit_bias), s), "vtp_siglip_pairs")
+    _lib.check(L.vtp_clip_grad_rows(_p(scratch), _p(txt_all), _p(logit_scale), _p(d_img_l), Bl, Bg, D, 0, s), "vtp_clip_grad_rows")
+    _lib.check(L.vtp_clip_grad_cols(_p(scratch), _p(img_l), _p(logit_scale), _p(d_txt_all), Bl, Bg, D, 0, s), "vtp_clip_grad_cols")
+
+
+def koleo(xn, nn_scratch, d_xn, loss_sum, B, D, weight, eps=1e-8):
+    _lib.check(_lib_().vtp_koleo(_p(xn), _p(nn_scratch), _p(d_xn), _p(loss_sum), B, D, weight, eps, _s()), "vtp_koleo")
+
+
+def sinkhorn_knopp(logits, inv_temp, probs, u, v, scratch, T, K, count, n_iters=3, phase=-1, count_dev=None, n_rows_dev=None):
+    _lib.check(_lib_().vtp_sinkhorn_knopp(_p(logits), inv_temp, _p(probs), _p(u), _p(v), _p(scratch), T, K, float(count), _p(count_dev),
+                                          _p(n_rows_dev), n_iters, phase, _s()), "vtp_sinkhorn_knopp")
+
+
 def gather_token_rows(src, idx, dst, T, D):
     _lib.check(_lib_().vtp_gather_token_rows(_p(src), _p(idx), _p(dst), T, D, _s()), "vtp_gather_token_rows")
 

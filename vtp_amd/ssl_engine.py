@@ -88,13 +88,15 @@ class DinoHeadEngine:
         dz_b = ws.get("b.dz_b", (T, bott), BF)
         ops.cast_f32_bf16(dz, dz_b, T * bott)
         dh = ws.get("b.dh", (T, hid), BF)
-        dpre = ws.get("b.dpre", (T, hid), BF)
+        # one d(pre-activation) buffer per layer: the weight-gradient branch of l2 (side stream, linear_bwd) may still be
+        # reading its dy while the main stream already produces l1's
+        dpre2, dpre1 = ws.get("b.dpre2", (T, hid), BF), ws.get("b.dpre1", (T, hid), BF)
         linear_bwd(ws, "l3", self.l3, dz_b, h2, T, dh)
-        ops.gelu_bwd(dh, pre2, dpre, T * hid)
-        linear_bwd(ws, "l2", self.l2, dpre, h1, T, dh)
-        ops.gelu_bwd(dh, pre1, dpre, T * hid)
+        ops.gelu_bwd(dh, pre2, dpre2, T * hid)
+        linear_bwd(ws, "l2", self.l2, dpre2, h1, T, dh)
+        ops.gelu_bwd(dh, pre1, dpre1, T * hid)
         dX = ws.get("b.dX", (T, self.Din), BF)
-        linear_bwd(ws, "l1", self.l1, dpre, X, T, dX)
+        linear_bwd(ws, "l1", self.l1, dpre1, X, T, dX)
         OVERLAP.join()
         return dX
 

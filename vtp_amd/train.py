@@ -82,7 +82,7 @@ def param_ranges(offsets, prefixes: Sequence[str]) -> List[Tuple[int, int]]:
 
 
 CLIP_PREFIXES = ("visual_proj.", "text_transformer.", "token_embedding.", "positional_embedding", "ln_final.",
-                 "text_projection", "logit_scale")
+                 "text_projection", "logit_scale", "logit_bias")
 
 
 class VTPTrainer:
@@ -94,7 +94,7 @@ class VTPTrainer:
                  rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
                  lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
-                 drop_seed: int = 0):
+                 drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
@@ -103,6 +103,12 @@ class VTPTrainer:
         # step) and the pixel decoder's drop_path_rate
         self.drop_rate, self.decoder_drop_rate = float(drop_rate), float(decoder_drop_rate)
         self._drop_gen = torch.Generator().manual_seed(int(drop_seed))
+        # SSL loss variants (DINOv2 conventions): teacher-target centring "softmax" (EMA centre) or
+        # "sinkhorn_knopp"; KoLeo regulariser on the student's global cls tokens (per view) with weight koleo_weight
+        if centering not in ("softmax", "sinkhorn_knopp"):
+            raise ValueError(f"centering must be 'softmax' or 'sinkhorn_knopp', got {centering!r}")
+        self.centering, self.koleo_weight, self.sk_iterations = centering, float(koleo_weight), int(sk_iterations)
+        self.koleo_loss_sum = None
         self.lpips, self.perceptual_weight = lpips, float(perceptual_weight)
         if self.perceptual_weight > 0 and lpips is None:
             raise ValueError("perceptual_weight > 0 needs an LPIPS module")
@@ -129,6 +135,7 @@ class VTPTrainer:
             self.center_ibot = torch.zeros(K, dtype=F32, device=st.device)
             self.center_stats = torch.zeros(2 * K + 8, dtype=F32, device=st.device)  # [sum_dino | sum_ibot | n_masked, pad]
             self.ssl_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
+            self.koleo_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
             self.momentum_dev = torch.zeros(4, dtype=F32, device=st.device)
         self._ssl_static = {}
         self.ssl_bucket = int(os.environ.get("VTP_SSL_BUCKET", "512"))  # masked-token rows are padded to a multiple of this
@@ -180,7 +187,7 @@ class VTPTrainer:
                 "trunk_head": rng("trunk.cls_token", "trunk.mask_token", "trunk.patch_embed."),
                 "text_tail": rng("ln_final.", "text_projection"),
                 "text_head": rng("token_embedding.", "positional_embedding"),
-                "clip_head": rng("visual_proj.", "logit_scale"), "dino_head": rng("dino_head.")}
+                "clip_head": rng("visual_proj.", "logit_scale", "logit_bias"), "dino_head": rng("dino_head.")}
         towers = [("dec", "pixel_decoder.blocks.", self.decoder.depth), ("trunk", "trunk.blocks.", self.trunk.depth)]
         if self.text is not None:
             towers.append(("text", "text_transformer.resblocks.", self.text.depth))
@@ -231,23 +238,28 @@ class VTPTrainer:
         ws = out["ws"]
         t_logits, s_logits = out["teacher_logits"], out["student_logits"]
         probs = ws.get("probs", (Tt, K), BF)
-        ops.softmax_center(t_logits, self.center_dino, 1.0 / self.teacher_temp, probs, B2, K)
-        ops.softmax_center(t_logits[B2:], self.center_ibot, 1.0 / self.teacher_temp, probs[B2:], Tm, K)
-        # centre statistics of this batch (teacher outputs), summed over ranks, then EMA
-        stats = self.center_stats
-        stats.zero_()
-        ops.colsum_bf16(t_logits, K, stats, B2, K)
-        # masked-patch rows: the first n_masked of the Tm padded rows, n_masked read from device memory (graph-replay safe)
-        ops.colsum_bf16_rows(t_logits[B2:], K, stats[K:], P["dev"]["n_masked_i"], Tm, K)
-        stats[2 * K:2 * K + 1].copy_(P["dev"]["n_masked_f"])
-        if self.world > 1:
-            yield lambda: dist.all_reduce(stats, group=self.group)
-        ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
-        ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
+        if self.centering == "sinkhorn_knopp":
+            yield from self._sinkhorn_targets(ws, t_logits, probs, P, B2, Tm, K)
+        else:
+            ops.softmax_center(t_logits, self.center_dino, 1.0 / self.teacher_temp, probs, B2, K)
+            ops.softmax_center(t_logits[B2:], self.center_ibot, 1.0 / self.teacher_temp, probs[B2:], Tm, K)
+            # centre statistics of this batch (teacher outputs), summed over ranks, then EMA
+            stats = self.center_stats
+            stats.zero_()
+            ops.colsum_bf16(t_logits, K, stats, B2, K)
+            # masked-patch rows: the first n_masked of the Tm padded rows, n_masked read from device memory (graph-replay safe)
+            ops.colsum_bf16_rows(t_logits[B2:], K, stats[K:], P["dev"]["n_masked_i"], Tm, K)
+            stats[2 * K:2 * K + 1].copy_(P["dev"]["n_masked_f"])
+            if self.world > 1:
+                yield lambda: dist.all_reduce(stats, group=self.group)
+            ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
+            ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
         d_logits = ws.get("d_logits", (Ts, K), BF)
         ops.dino_ce(s_logits, probs, P["dev"]["t0"], P["dev"]["t1"], P["dev"]["w"], 1.0 / self.student_temp, self.ssl_loss_sum,
                     d_logits, Ts, K)
         dX = head.backward(d_logits, out["head_ctx"])
+        if self.koleo_weight > 0:  # KoLeo on the student's global cls tokens = rows [nl, nl + B2) of the head input, per view
+            self._koleo(ws, out["Xs"], dX, nl, B2, D)
         yield ["dino_head"]
         ctx = out["ctx"]
         d_xnf = self.trunk.d_xnf_buffer(ctx)
@@ -256,6 +268,54 @@ class VTPTrainer:
         ops.scatter_token_rows(dX, P["dev"]["student_local_src"], d_xnf[seg_l.row0:], nl, D)
         ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_xnf[seg_g.row0:], Ts - nl, D)
         return out
+
+    def _sinkhorn_targets(self, ws, t_logits, probs, P, B2, Tm, K):
+        """Sinkhorn-Knopp teacher targets (DINOv2 sinkhorn_knopp_teacher) for the cls rows and for the masked-patch rows.  Under
+        data parallelism the per-prototype sums, the running maximum and the sample count are all-reduced between the phases
+        (the normalisation runs over the GLOBAL batch), exactly where DINOv2 calls dist.all_reduce."""
+        dist = self.bucketer.dist
+        it = self.sk_iterations
+        inv_t = 1.0 / self.teacher_temp
+        for tag, lg, pr, T, cnt_dev, rows_dev, count in (("cls", t_logits, probs, B2, None, None, float(B2 * self.world)),
+                                                         ("patch", t_logits[B2:], probs[B2:], Tm, P["dev"]["n_masked_f"],
+                                                          P["dev"]["n_masked_i"], 0.0)):
+            u, v = ws.get(f"sk.u.{tag}", (T,), F32), ws.get(f"sk.v.{tag}", (K,), F32)
+            scr = ws.get(f"sk.s.{tag}", (8 + K + T,), F32)
+            if self.world == 1:
+                ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, it, -1, cnt_dev, rows_dev)
+                continue
+            if cnt_dev is not None:  # global masked-token count
+                gcnt = ws.get("sk.cnt", (1,), F32)
+                gcnt.copy_(cnt_dev)
+                yield lambda gcnt=gcnt: dist.all_reduce(gcnt, group=self.group)
+                cnt_dev = gcnt
+            ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, 0, 0, cnt_dev, rows_dev)
+            yield lambda scr=scr: dist.all_reduce(scr[:1], op=dist.ReduceOp.MAX, group=self.group)
+            for i in range(it):
+                ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, i, 1, cnt_dev, rows_dev)
+                yield lambda scr=scr: dist.all_reduce(scr[8:8 + K], group=self.group)
+                ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, i, 2, cnt_dev, rows_dev)
+            ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, it, 3, cnt_dev, rows_dev)
+
+    def _koleo(self, ws, Xs, dX, nl, B2, D):
+        """koleo_weight * sum over the two views of KoLeoLoss(student global cls tokens): adds its gradient to the head-input
+        gradient rows of those tokens (dX bf16) -- the tokens are the final-norm trunk outputs, so it flows on into the trunk."""
+        B = B2 // 2
+        self.koleo_loss_sum.zero_()
+        x32 = ws.get("kl.x", (B2, D), F32)
+        x32.copy_(Xs[nl:nl + B2])
+        xn, inv = ws.get("kl.xn", (B2, D), F32), ws.get("kl.inv", (B2,), F32)
+        ops.l2norm_fwd(x32, xn, inv, B2, D, 1e-8)
+        d_xn = ws.get("kl.dxn", (B2, D), F32)
+        d_xn.zero_()
+        nn = ws.get("kl.nn", (B2,), torch.int32)
+        for v in range(2):
+            ops.koleo(xn[v * B:], nn[v * B:], d_xn[v * B:], self.koleo_loss_sum, B, D, self.koleo_weight / B)
+        dx = ws.get("kl.dx", (B2, D), F32)
+        ops.l2norm_bwd(d_xn, xn, inv, dx, B2, D)
+        dxb = ws.get("kl.dxb", (B2, D), BF)
+        dxb.copy_(dx)
+        dX[nl:nl + B2].add_(dxb)
 
     def prepare_ssl(self, global_crops: torch.Tensor, local_crops: torch.Tensor, masks, pad_to: Optional[int] = None,
                     upperbound: Optional[int] = None) -> dict:
@@ -339,8 +399,16 @@ class VTPTrainer:
             d_img_all = cw.get("d_img_all", (Bg, Dt), F32)
             d_txt_all = cw.get("d_txt_all", (Bg, Dt), F32)
             scratch = cw.get("logits", (2 * B * Bg,), F32)
-            ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
-                          d_img_l, d_txt_l, d_img_all, d_txt_all, st.g("logit_scale"), scratch)
+            if st.has("logit_bias"):
+                # SigLIP (logit_bias present, vtp.py:185-188): every (local image, any text) pair once across the ranks; the text
+                # side gets its gradient through the gathered columns only
+                ops.siglip_loss(img_n, txt_all, st.p("logit_scale"), st.p("logit_bias"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
+                                d_img_l, d_txt_all, st.g("logit_scale"), st.g("logit_bias"), scratch)
+                d_txt_l.zero_()
+                d_img_all.zero_()
+            else:
+                ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
+                              d_img_l, d_txt_l, d_img_all, d_txt_all, st.g("logit_scale"), scratch)
             if self.world > 1:
                 rs_i = cw.get("rs_i", (B, Dt), F32)
                 rs_t = cw.get("rs_t", (B, Dt), F32)
@@ -358,6 +426,8 @@ class VTPTrainer:
                 d_img_l.mul_(self.clip_weight)
                 d_txt_l.mul_(self.clip_weight)
                 st.g("logit_scale").mul_(self.clip_weight)
+                if st.has("logit_bias"):
+                    st.g("logit_bias").mul_(self.clip_weight)
             d_f_txt = self.clip.normalize_bwd(d_txt_l, txt_n, inv_t, "txt")
             if par_bwd:  # whole text backward on the text stream; its buckets are announced once it has been joined
                 T.wait_stream(main)
