@@ -234,6 +234,18 @@ int vtp_koleo(const float* xn, int* nn_scratch, float* d_xn, float* loss_sum, in
 int vtp_sinkhorn_knopp(const void* logits, float inv_temp, void* probs, float* u, float* v, float* scratch, int T, int K, float count,
                        const float* count_dev, const int* n_rows_dev, int n_iters, int phase, void* stream);
 
+/* ---- tokenizer boundary (tokenizer.hip): the byte-image ends of generation/tokenizer/vtp_tokenizer.py --------
+ * vtp_u8_to_images: ToTensor + Normalize(mean, std) (+ horizontal flip) of img_transform (vtp_tokenizer.py:74-81):
+ *   img[b,c,y,x] = (float(u8[b,y,xs,c]) / 255 - mean[c]) / std[c], xs = flip ? W-1-x : x.   u8 NHWC -> f32 NCHW, W % 4 == 0.
+ * vtp_images_to_u8: the tail of decode_to_images (vtp_tokenizer.py:105-111): Normalize(sub, div) -> * 255 -> clamp(0,255) ->
+ *   uint8 (truncation) -> NHWC.   mean3 / std3 / sub3 / div3 are HOST pointers to 3 floats.
+ * vtp_latent_channel_stats: sums[0..C) += sum, sums[C..2C) += sum of squares of latents f32 [B, C, hw] per channel, in fp64
+ *   (the latents_stats.pt mean / std of the LightningDiT latent dataset, extract_features_vtp.py:124-126). */
+int vtp_u8_to_images(const void* u8_nhwc, float* img_nchw, long B, int H, int W, const float* mean3, const float* std3, int flip,
+                     void* stream);
+int vtp_images_to_u8(const float* img_nchw, void* u8_nhwc, long B, int H, int W, const float* sub3, const float* div3, void* stream);
+int vtp_latent_channel_stats(const float* latents, double* sums, long B, int C, int hw, void* stream);
+
 /* ---- self-supervised (DINO / iBOT) head (ssl.hip) -----------------------------------------------------------
  * Token buffers of VTP.get_teacher_forward_outputs / get_student_ssl_outputs (vtp.py:432-439,470-473):
  * dst bf16 [T, D] row t = src row idx[t] (idx[t] < 0: zero row); scatter is the backward (indices are unique). */

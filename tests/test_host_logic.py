@@ -229,3 +229,37 @@ def test_drop_allocation_matches_reference_rule():
         for rank in range(W):
             k, sc = Stack.drop_allocation(b, r, W, rank)
             assert k == alloc[rank] and abs(sc - gb / sum(alloc)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ f3: tokenizer host logic
+def test_distributed_indices_match_torch_sampler():
+    """extract_features_vtp.py:59-62 uses DistributedSampler(shuffle=False): same rank slices, wrap-around padding included"""
+    from torch.utils.data.distributed import DistributedSampler
+    from vtp_amd.tokenizer import distributed_indices
+    for n in (1, 2, 7, 8, 13, 100):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
+                assert distributed_indices(n, world, rank) == ref, (n, world, rank)
+
+
+def test_latent_shard_writer_layout(tmp_path):
+    """file names, keys, metadata and the 10000 // batch_size flush rule of extract_features_vtp.py:88-118"""
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+    from vtp_amd.tokenizer import LatentShardWriter, shard_name
+    w = LatentShardWriter(str(tmp_path), rank=3, batch_size=4000)
+    assert w.batches_per_shard == 2
+    for i in range(3):
+        w.add(torch.full((2, 4, 2, 2), float(i)), torch.full((2, 4, 2, 2), -float(i)), torch.tensor([i, i + 10]))
+    assert w.saved_files == 1
+    last = w.close()
+    assert os.path.basename(last) == "latents_rank03_shard001.safetensors" == shard_name(3, 1)
+    assert w.close() is None
+    a = load_file(os.path.join(str(tmp_path), shard_name(3, 0)))
+    assert a["latents"].shape == (4, 4, 2, 2) and a["labels"].tolist() == [0, 10, 1, 11]
+    assert torch.equal(a["latents_flip"], -a["latents"])
+    with safe_open(last, "pt") as f:
+        assert f.metadata() == {"total_size": "2", "dtype": "torch.float32", "device": "cpu"}
+    with pytest.raises(ValueError):
+        LatentShardWriter(str(tmp_path), batch_size=20000)

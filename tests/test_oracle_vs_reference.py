@@ -125,3 +125,20 @@ def test_layerscale_and_stochastic_depth_branch():
         o = O.trunk_forward(sd, img, 2, use_bottleneck=False, drop=drop)
     torch.testing.assert_close(o["x_norm_patchtokens"], r["x_norm_patchtokens"], rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(o["x_norm_clstoken"], r["x_norm_clstoken"], rtol=2e-4, atol=2e-5)
+
+
+def test_center_crop_arr_matches_reference():
+    """vtp_amd.tokenizer.center_crop_arr vs vtp/utils/image_utils.py:5-33 (pure PIL / numpy: imported straight from the tree)"""
+    import importlib.util
+
+    import numpy as np
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("_ref_image_utils", "/root/reference/vtp/utils/image_utils.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    from vtp_amd.tokenizer import center_crop_arr
+    rng = np.random.default_rng(0)
+    for (h, w), size in [((300, 500), 64), ((64, 64), 64), ((130, 97), 48), ((1000, 700), 96), ((50, 80), 64)]:
+        im = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        a, b = np.asarray(center_crop_arr(im, size)), np.asarray(ref.center_crop_arr(im, size))
+        assert a.shape == (size, size, 3) and np.array_equal(a, b)

@@ -16,6 +16,9 @@ def __getattr__(name):  # lazy: importing the package must not require torch.cud
     if name == "LPIPS":
         from .lpips import LPIPS
         return LPIPS
+    if name == "VTP_Tokenizer":
+        from .tokenizer import VTP_Tokenizer
+        return VTP_Tokenizer
     if name == "VTPTrainer":
         from .train import VTPTrainer
         return VTPTrainer

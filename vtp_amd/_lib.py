@@ -44,6 +44,9 @@ SIGNATURES = {
     "vtp_layerscale_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vtp_scaled_transpose": [_P, _P, _P, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
+    "vtp_u8_to_images": [_P, _P, _L, _I, _I, _P, _P, _I, _P],
+    "vtp_images_to_u8": [_P, _P, _L, _I, _I, _P, _P, _P],
+    "vtp_latent_channel_stats": [_P, _P, _L, _I, _I, _P],
     "vtp_ema": [_P, _P, _L, _F, _P],
     "vtp_gather_token_rows": [_P, _P, _P, _I, _I, _P],
     "vtp_scatter_token_rows": [_P, _P, _P, _I, _I, _P],

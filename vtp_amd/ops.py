@@ -301,3 +301,28 @@ def maxpool2_bwd(Y, dP, tap, dY, NB, H, W, C):
 
 def lpips_tap(f0, f1, w, val, df0, n, H, W, C, gscale):
     _lib.check(_lib_().vtp_lpips_tap(_p(f0), _p(f1), _p(w), _p(val), _p(df0), n, H, W, C, float(gscale), _s()), "vtp_lpips_tap")
+
+
+def _f3(vals):
+    import ctypes
+    return (ctypes.c_float * 3)(*[float(v) for v in vals])
+
+
+def u8_to_images(u8_nhwc, img_nchw, mean, std, flip=False):
+    """ToTensor + Normalize (+ horizontal flip): uint8 [B,H,W,3] -> f32 [B,3,H,W]  (vtp_tokenizer.py:74-81)"""
+    B, H, W, _ = u8_nhwc.shape
+    m, s = _f3(mean), _f3(std)
+    _lib.check(_lib_().vtp_u8_to_images(_p(u8_nhwc), _p(img_nchw), B, H, W, m, s, int(bool(flip)), _s()), "vtp_u8_to_images")
+
+
+def images_to_u8(img_nchw, u8_nhwc, sub, div):
+    """Normalize(sub, div) -> *255 -> clamp -> uint8 -> NHWC  (vtp_tokenizer.py:105-111)"""
+    B, _, H, W = img_nchw.shape
+    a, d = _f3(sub), _f3(div)
+    _lib.check(_lib_().vtp_images_to_u8(_p(img_nchw), _p(u8_nhwc), B, H, W, a, d, _s()), "vtp_images_to_u8")
+
+
+def latent_channel_stats(latents, sums):
+    B, C = latents.shape[:2]
+    hw = latents[0, 0].numel()
+    _lib.check(_lib_().vtp_latent_channel_stats(_p(latents), _p(sums), B, C, hw, _s()), "vtp_latent_channel_stats")
