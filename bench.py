@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-lpips-run", action="store_true", help="skip the second measurement with the perceptual term on")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + rank-sharded AdamW + parameter all-gather instead of all-reduce + replicated AdamW")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="gradient bucket dtype (bf16: --shard-optimizer only)")
+    ap.add_argument("--dist-timeout", type=int, default=600, help="seconds before a stuck collective aborts the job (no silent hang)")
     ap.add_argument("--prototypes", type=int, default=65536, help="DINO head out_dim K (DINOv2 default 65536; unpinned)")
     ap.add_argument("--perceptual-weight", type=float, default=0.0,
                     help="> 0: add the LPIPS perceptual term (VGG16, seeded random weights: vgg.pth is a download) to the rec loss")
@@ -204,11 +208,23 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")               # RCCL prints its version banner on rank 0
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")  # a timed-out collective tears the process down (no hang)
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        # every rank must have arrived with the same idea of the job before any timing starts
+        seen = torch.zeros(world, dtype=torch.int32, device=dev)
+        seen[rank] = 1 + local
+        dist.all_reduce(seen)
+        if rank == 0:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "-"
+            print(f"[bench] {world} ranks up (backend {backend}, RCCL {ver}); local devices {[int(v) - 1 for v in seen.tolist()]}",
+                  file=sys.stderr, flush=True)
 
     from vtp_amd import VTP, VTPConfig, VTPModel, VTPTrainer, ops
     cfg_kw, B, res, objectives = WORKLOADS[args.workload]
@@ -228,7 +244,8 @@ def main():
             from vtp_amd import LPIPS
             lp = LPIPS().reset_parameters(0).to(dev)
         trainer = VTPTrainer(model, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, use_graphs=use_graphs, lpips=lp,
-                             perceptual_weight=perceptual_weight)
+                             perceptual_weight=perceptual_weight, shard_optimizer=args.shard_optimizer and world > 1,
+                             grad_dtype=args.grad_dtype if (args.shard_optimizer and world > 1) else "fp32")
         txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
         return model, lp, trainer, txt
 
@@ -264,11 +281,19 @@ def main():
             for _ in range(warmup):
                 one_step(trainer, txt)
             sync()
+        trainer.time_comm = world > 1  # HIP events around every point where the main stream waits for a collective
+        trainer.bucketer.comm_bytes = 0
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, closs = one_step(trainer, txt)
         sync()
         elapsed = time.perf_counter() - t0
+        if world > 1:
+            state["comm"] = {"exposed_ms_per_step": round(trainer.comm_exposed_ms() / steps, 3),
+                             "payload_mb_per_step": round(trainer.bucketer.comm_bytes / steps / 1e6, 1),
+                             "gradient_exchange": ("reduce-scatter (" + args.grad_dtype + ") + rank-sharded AdamW + fp32 parameter all-gather")
+                             if trainer.shard_optimizer else "bucketed fp32 all-reduce + replicated AdamW"}
+            trainer.time_comm = False
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -276,6 +301,7 @@ def main():
         return model, lp, trainer, txt, launch, elapsed, loss, closs
 
     model, lp, trainer, txt, launch, elapsed, loss, closs = measure(args.perceptual_weight, args.steps, args.warmup)
+    state["comm_main"] = state.pop("comm", None)  # rank 0's main-stream waits (the second, LPIPS-on measurement overwrites "comm")
     ssl = None
     if do_ssl:  # the instrumented step below reuses the last drawn batch
         masks, upper = mask_stream.draw()
@@ -412,6 +438,7 @@ def main():
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
         "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info, "lpips_on": lpips_on,
+        "comm": state.get("comm_main"),
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),
     }

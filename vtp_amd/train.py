@@ -37,7 +37,7 @@ class GradBucketer:
 
     Pure torch.distributed (works with gloo on CPU for tests, nccl==RCCL on MI355X)."""
 
-    def __init__(self, flat_g: torch.Tensor, group=None):
+    def __init__(self, flat_g: torch.Tensor, group=None, shard: bool = False, grad_dtype: torch.dtype = torch.float32):
         import torch.distributed as dist
         self.dist = dist
         self.flat_g = flat_g
@@ -46,19 +46,85 @@ class GradBucketer:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.works = []
         self.reduced_elems = 0
+        # sharded mode (reduce-scatter + rank-sharded AdamW + parameter all-gather): every bucket [lo, hi) is cut into
+        # `world` equal chunks (8-element aligned, the last one zero-padded); rank r owns chunk r of every bucket
+        self.shard = bool(shard) and self.world > 1
+        self.grad_dtype = grad_dtype
+        self.shards: dict = {}      # (lo, hi) -> ShardRec
+        self.comm_bytes = 0
+
+    class ShardRec:
+        __slots__ = ("lo", "hi", "chunk", "a", "b", "send", "g_out", "g32", "p_send", "p_recv")
+
+    def _rec(self, lo: int, hi: int):
+        rec = self.shards.get((lo, hi))
+        if rec is None:
+            rec = self.ShardRec()
+            n, W, dev = hi - lo, self.world, self.flat_g.device
+            rec.lo, rec.hi = lo, hi
+            rec.chunk = (n + W * 8 - 1) // (W * 8) * 8
+            rec.a = min(lo + self.rank * rec.chunk, hi)
+            rec.b = min(rec.a + rec.chunk, hi)
+            rec.send = torch.zeros(rec.chunk * W, dtype=self.grad_dtype, device=dev)   # padded copy / cast of the gradients
+            rec.g_out = torch.zeros(rec.chunk, dtype=self.grad_dtype, device=dev)      # this rank's reduced chunk
+            rec.g32 = rec.g_out if self.grad_dtype == torch.float32 else torch.zeros(rec.chunk, dtype=torch.float32, device=dev)
+            rec.p_send = torch.zeros(rec.chunk, dtype=torch.float32, device=dev)
+            rec.p_recv = torch.zeros(rec.chunk * W, dtype=torch.float32, device=dev)
+            self.shards[(lo, hi)] = rec
+        return rec
+
+    def native(self) -> bool:
+        return self.dist.get_backend(self.group) == "nccl"
+
+    def reduce_scatter_range(self, lo: int, hi: int):
+        """Launch (async) the sum-reduce-scatter of flat_g[lo:hi]: rank r receives chunk r in rec.g_out."""
+        rec = self._rec(lo, hi)
+        n = hi - lo
+        if self.grad_dtype == torch.float32:
+            rec.send[:n].copy_(self.flat_g[lo:hi])
+        else:
+            ops.cast_f32_bf16(self.flat_g[lo:hi], rec.send, n)
+        if self.native():
+            w = self.dist.reduce_scatter_tensor(rec.g_out, rec.send, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append((w, None))
+        else:  # gloo has no reduce-scatter (and no bf16 on device tensors): all-reduce in fp32, keep the own chunk
+            tmp = rec.send.float()
+            w = self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append((w, lambda: rec.g_out.copy_(tmp[self.rank * rec.chunk:(self.rank + 1) * rec.chunk])))
+        self.reduced_elems += n
+        self.comm_bytes += n * rec.send.element_size()
 
     def reduce_range(self, lo: int, hi: int):
         """Launch (async) sum-all-reduce of flat_g[lo:hi]."""
         if self.world == 1 or hi <= lo:
             return
+        if self.shard:
+            return self.reduce_scatter_range(lo, hi)
         w = self.dist.all_reduce(self.flat_g[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.works.append(w)
+        self.works.append((w, None))
         self.reduced_elems += hi - lo
+        self.comm_bytes += (hi - lo) * 4
 
     def wait(self):
-        for w in self.works:
+        for w, after in self.works:
             w.wait()
+            if after is not None:
+                after()
         self.works = []
+
+    def all_gather_params(self, flat_p: torch.Tensor, recs):
+        """Every rank contributes its (freshly updated) chunk of each bucket; afterwards rec.p_recv holds the whole bucket."""
+        works = []
+        for rec in recs:
+            if self.native():
+                works.append((self.dist.all_gather_into_tensor(rec.p_recv, rec.p_send, group=self.group, async_op=True), None))
+            else:
+                rec.p_recv.zero_()
+                rec.p_recv[self.rank * rec.chunk:(self.rank + 1) * rec.chunk].copy_(rec.p_send)
+                works.append((self.dist.all_reduce(rec.p_recv, group=self.group, async_op=True), None))
+            self.comm_bytes += rec.p_recv.numel() * 4
+        for w, _ in works:
+            w.wait()
 
 
 def merge_ranges(ranges: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
@@ -94,7 +160,8 @@ class VTPTrainer:
                  rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
                  lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
-                 drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3):
+                 drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3,
+                 shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32"):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
@@ -144,7 +211,19 @@ class VTPTrainer:
         self.step_no = 0
         self.loss_sum = torch.zeros(1, dtype=F32, device=st.device)       # L1 numerator
         self.clip_loss_sum = torch.zeros(1, dtype=F32, device=st.device)  # contrastive loss (already a mean)
-        self.bucketer = GradBucketer(st.flat_g, group)
+        # data-parallel gradient exchange: "all-reduce + replicated AdamW" (default) or, with shard_optimizer (env
+        # VTP_SHARD_OPT=1), "reduce-scatter + AdamW on this rank's 1/world of every bucket + parameter all-gather"; grad_dtype
+        # "bf16" halves the reduce-scatter volume (sharded mode only; the local fp32 gradients are rounded once before the sum)
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("VTP_SHARD_OPT", "0") == "1"
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_dtype must be 'fp32' or 'bf16', got {grad_dtype!r}")
+        if grad_dtype == "bf16" and not shard_optimizer:
+            raise ValueError("grad_dtype='bf16' needs shard_optimizer=True (the all-reduce path reduces the flat fp32 buffer in place)")
+        self.bucketer = GradBucketer(st.flat_g, group, shard=shard_optimizer, grad_dtype=BF if grad_dtype == "bf16" else F32)
+        self.shard_optimizer = self.bucketer.shard
+        self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
+        self._comm_events = []
         self.world, self.rank, self.group = self.bucketer.world, self.bucketer.rank, group
         self.bucket_blocks = bucket_blocks
         self._bucket_plan = self._plan_buckets()
@@ -339,6 +418,15 @@ class VTPTrainer:
                     plan=plan, dev=plan_to_device(plan, dev))
 
     def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
+        """_step_body plus the bookkeeping of which flat ranges have been handed to the gradient exchange so far (known at
+        generator time, i.e. also while the body is being captured into hipGraph segments and no collective runs)."""
+        self._reduced_ranges = []
+        for ev in self._step_body(images, text, ssl):
+            if not callable(ev):
+                self._reduced_ranges += merge_ranges([r for k in ev if k != "FINAL" for r in self._bucket_plan[k]])
+            yield ev
+
+    def _step_body(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
         st = self.store
         dist = self.bucketer.dist
         B, _, H, W = images.shape
@@ -481,9 +569,22 @@ class VTPTrainer:
         yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
         yield ["trunk_head", "FINAL"]
         # ---- optimizer (after every bucket has been reduced)
-        ranges = list(self.ranges_all if text is not None else self.ranges_rec) + (self.ranges_ssl if ssl is not None else [])
-        for lo, hi in merge_ranges(ranges):
-            ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
+        ranges = merge_ranges(list(self.ranges_all if text is not None else self.ranges_rec) + (self.ranges_ssl if ssl is not None else []))
+        if self.shard_optimizer:
+            recs = self._shard_recs(ranges)
+            for rec in recs:  # AdamW on this rank's chunk of every bucket (moments outside the own chunks are never touched)
+                n = rec.b - rec.a
+                if n > 0:
+                    if rec.g32 is not rec.g_out:
+                        rec.g32.copy_(rec.g_out)
+                    ops.adamw_dev(st.flat_p[rec.a:rec.b], rec.g32, self.m[rec.a:rec.b], self.v[rec.a:rec.b], None, n, self.hyper)
+                    rec.p_send[:n].copy_(st.flat_p[rec.a:rec.b])
+            yield lambda: self.bucketer.all_gather_params(st.flat_p, recs)
+            for rec in recs:
+                st.flat_p[rec.lo:rec.hi].copy_(rec.p_recv[:rec.hi - rec.lo])
+        else:
+            for lo, hi in ranges:
+                ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
@@ -518,6 +619,50 @@ class VTPTrainer:
             dist.all_reduce(tmp, group=self.group)
             out.copy_(tmp[self.rank * B:(self.rank + 1) * B])
 
+    def _shard_recs(self, opt_ranges):
+        """The buckets reduce-scattered during this step; together they must cover exactly what the optimizer updates."""
+        recs = [self.bucketer._rec(lo, hi) for lo, hi in self._reduced_ranges]
+        got = merge_ranges(self._reduced_ranges)
+        if got != list(opt_ranges):
+            raise RuntimeError(f"sharded optimizer: reduced gradient ranges {got} differ from the optimizer's ranges {list(opt_ranges)}")
+        return recs
+
+    def _timed(self, fn):
+        """run a point where the main stream has to wait for RCCL; with time_comm the wait is bracketed by HIP events"""
+        if not self.time_comm:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._comm_events.append((e0, e1))
+        return out
+
+    def comm_exposed_ms(self, reset: bool = True) -> float:
+        """total time the main stream spent waiting for collectives since the last call (needs time_comm; synchronises)"""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._comm_events)
+        if reset:
+            self._comm_events = []
+        return ms
+
+    def _gather_moments(self):
+        """sharded mode: the Adam moments of a chunk live on its owner only -- assemble the full buffers (checkpointing)"""
+        if not self.shard_optimizer or not self.bucketer.shards:
+            return self.m, self.v
+        full = []
+        for buf in (self.m, self.v):
+            out = buf.clone()
+            for rec in self.bucketer.shards.values():
+                n = rec.b - rec.a
+                rec.p_send.zero_()
+                if n > 0:
+                    rec.p_send[:n].copy_(buf[rec.a:rec.b])
+                self.bucketer.all_gather_params(None, [rec])
+                out[rec.lo:rec.hi].copy_(rec.p_recv[:rec.hi - rec.lo])
+            full.append(out)
+        return full
+
     def _set_hyper(self):
         self.step_no += 1
         b1, b2 = self.betas
@@ -531,12 +676,12 @@ class VTPTrainer:
 
     def _handle(self, ev):
         if callable(ev):
-            ev()
+            self._timed(ev)
             return
         final = "FINAL" in ev
         self._reduce([k for k in ev if k != "FINAL"])
         if final:
-            self.bucketer.wait()  # the generator's next (last) leg is the optimizer
+            self._timed(self.bucketer.wait)  # the generator's next (last) leg is the optimizer
 
     def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None, ssl: Optional[dict] = None):
         """One optimizer step.  images: f32 [B,3,H,W]; text: int64 [B, context_length] or None; ssl: prepare_ssl(...)
@@ -579,9 +724,10 @@ class VTPTrainer:
         """Optimizer moments (as name -> tensor, the same keys as model.state_dict()), step counter and SSL centres."""
         st = self.store
         sd = {"step": self.step_no, "exp_avg": {}, "exp_avg_sq": {}}
+        m, v = self._gather_moments()
         for name, (o, k) in st.offsets.items():
-            sd["exp_avg"][name] = self.m[o:o + k].detach().clone().view(st.params[name].shape).cpu()
-            sd["exp_avg_sq"][name] = self.v[o:o + k].detach().clone().view(st.params[name].shape).cpu()
+            sd["exp_avg"][name] = m[o:o + k].detach().clone().view(st.params[name].shape).cpu()
+            sd["exp_avg_sq"][name] = v[o:o + k].detach().clone().view(st.params[name].shape).cpu()
         if self.ssl_head is not None:
             sd["center_dino"], sd["center_ibot"] = self.center_dino.cpu().clone(), self.center_ibot.cpu().clone()
         return sd
