@@ -325,7 +325,7 @@ def main():
             M = kw["M"] if kw.get("M") is not None else a.shape[0]
             K = kw["K"] if kw.get("K") is not None else a.shape[1]
             N = kw["N"] if kw.get("N") is not None else b.shape[0]
-            recs.append((2.0 * M * N * K, e0, e1))
+            recs.append((2.0 * M * N * K, e0, e1, (fn.__name__, M, N, K, kw.get("epi", 0), kw.get("splits", 1))))
         return run
 
     def timed_qkv(a, w, bias, c, M, N, K, *rest):
@@ -333,7 +333,7 @@ def main():
         e0.record()
         orig_qkv(a, w, bias, c, M, N, K, *rest)
         e1.record()
-        recs.append((2.0 * M * N * K, e0, e1))
+        recs.append((2.0 * M * N * K, e0, e1, ("gemm_qkv_rope", M, N, K, 0, 1)))
 
     if rank == 0:
         ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope = timed(orig_nt), timed(orig_tn), timed_qkv
@@ -350,6 +350,17 @@ def main():
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12
+        if os.environ.get("VTP_BENCH_GEMM_TABLE"):  # per-shape in-situ table of the instrumented step (tuning aid)
+            tab = {}
+            for f, a, b, key in recs:
+                t = tab.setdefault(key, [0, 0.0, 0.0])
+                t[0] += 1
+                t[1] += a.elapsed_time(b)
+                t[2] += f
+            with open(os.environ["VTP_BENCH_GEMM_TABLE"], "w") as fh:
+                for key, (n, t, f) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"{key[0]:14s} M={key[1]:6d} N={key[2]:6d} K={key[3]:6d} epi={key[4]} splits={key[5]:2d}  calls={n:3d}  "
+                             f"total={t:7.3f} ms  avg={t / n * 1e3:7.1f} us  {f / t / 1e9:7.1f} TF/s\n")
         traffic, traffic_src = None, None
         pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (2, 1)) if os.path.exists(q)), "")
         if pmc and args.workload == "vtp_base_full" and not args.batch:

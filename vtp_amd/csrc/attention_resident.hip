@@ -11,6 +11,8 @@
 //
 // Forward is two-pass over the resident keys (row maximum first, then exp / sum / PV): no running rescale of the accumulator.
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include "vtp_hip.h"
 
@@ -19,6 +21,7 @@ namespace vtp {
 constexpr float LOG2E_R = 1.4426950408889634f;
 constexpr float LN2_R = 0.6931471805599453f;
 constexpr int RES_MAXN = 320;
+constexpr int RES_SPLIT_COLS = 4;  // valid queries of an odd last tile up to which it is split over the waves (fwd v2)
 
 struct AttnResArgs {
   const bf16 *q, *k, *v, *o, *d_o;
@@ -89,6 +92,28 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
   }
 }
@@ -119,7 +144,7 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + p.npad * 128;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6, hi = lane >> 5;  // wave: an SGPR (uniform branches, scalar wait counts)
   const int h = blockIdx.x, b = blockIdx.y;
   const bf16* qb = p.q + (long)b * p.sb + h * 64;
   const int q0 = (blockIdx.z * nwaves + wave) * 32, qi = q0 + (lane & 31);  // a head's query blocks are split over gridDim.z
@@ -198,6 +223,320 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
       *(bf16x4*)(orow + db * 32 + 8 * g + 4 * hi) = __builtin_convertvector(v, bf16x4);
     }
   if (hi == 0 && p.lse) p.lse[((long)b * p.heads + h) * p.N + qi] = (m2 + log2f(l)) * LN2_R;
+}
+
+// ------------------------------------------------------------------------------------------------ forward, v2
+// One wave owns T = 2 query tiles (64 queries): every K / V fragment read from LDS feeds both tiles, and the two tiles are
+// independent instruction streams.  Single pass with a running maximum (online softmax): the accumulator is rescaled only when a
+// maximum in the wave moved.  The softmax row of a query is split over lane (keys 4hi + ..) and lane ^ 32: v_permlane32_swap
+// exchanges the halves.
+//
+// Work split of one (image, head): waves = floor(tiles / 2), each with two full tiles against ALL key blocks.  An odd last tile
+// (N = 257 = 8 x 32 + 1: one valid query) would cost a fifth wave a whole tile of work on one SIMD -- instead every wave takes
+// that tile against a quarter of the key blocks, and the partial (max, sum, O) are merged through a few hundred bytes of LDS
+// (split-K over the keys, only the valid columns travel).  4 waves x <= 256 VGPRs and 74 KB of LDS: two workgroups share a CU,
+// one's staging / stores under the other's key loop.
+__device__ __forceinline__ float both_halves_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float both_halves_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// v_max3_f32 without the NaN-quieting v_max x, x the compiler puts in front of fmaxf operands (scores are finite or -inf)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2f(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// online-softmax key loop over blocks kb0, kb0 + step, ... < nkb for T query tiles; m in the log2 domain (scores * sc2).
+// The VALU work per score is what bounds this kernel (16 v_exp_f32 per lane and tile at quarter rate = the time of the tile's
+// 8 MFMAs), so everything around the exponentials is kept to packed / 3-operand instructions: 8 v_max3, 8 v_pk_fma, 8 v_pk_add,
+// 8 v_cvt_pk_bf16 per tile and key block.
+// stream_ops > 0: K / V arrive by LDS-DMA behind the loop, key block by key block, `stream_ops` vector-memory operations of this
+// wave per block (issued in block order; blocks 0 and 1 have landed before the loop): block kb is ready once at most
+// stream_ops * (nkb - 1 - kb) operations of every wave are outstanding.
+constexpr float LAZY_LOG2 = 6.f;
+
+template <int T>
+__device__ __forceinline__ void attn_key_loop(const char* Ks, const char* Vs, const bf16x8 (&qf)[T][4], int N, int nkb, int kb0, int step,
+                                              float sc2, int lane, f32x16 (&oacc)[T][2], float (&m)[T], float (&l)[T],
+                                              int stream_ops = 0) {
+  const int hi = lane >> 5, last = nkb - 1;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f32x2 sc2v = {sc2, sc2};
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    oacc[t][0] = zero;
+    oacc[t][1] = zero;
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+  }
+  for (int kb = kb0; kb < nkb; kb += step) {
+    // the stream arrives faster than the loop consumes it: two sync points (after blocks 0-1: blocks 2-4, then the rest) instead
+    // of a counted wait + barrier in front of every block
+    if (stream_ops > 0 && (kb == 2 || kb == 5)) {
+      wait_vmcnt_upto(__builtin_amdgcn_readfirstlane(kb == 2 ? stream_ops * max(nkb - 5, 0) : 0));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    f32x16 s[T];
+    {
+      bf16x8 kf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_row(Ks, kb * 32, ks, lane);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], zero, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[t][ks], s[t], 0, 0, 0);
+      }
+    }
+    // V^T fragments of this block: issued now, landed by the time the probabilities are packed
+    bf16x8 vf[2][2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) vf[db][ks] = frag_tr(Vs, db, kb * 32, ks, lane);
+    if (kb == last && (N & 31)) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) s[t][r] = -INFINITY;
+    }
+    float mn[T];
+    bool moved = false;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float bm = max3f(s[t][0], s[t][1], s[t][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) bm = max3f(bm, s[t][r], s[t][r + 1]);
+      bm = max2f(bm, s[t][15]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bm), __float_as_uint(bm), false, false);
+      bm = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      // lazy running maximum: it follows the block maximum only when that exceeds it by more than 2^LAZY -- until then the
+      // probabilities are merely scaled by up to 2^LAZY (exact in fp32 / bf16: a power-of-two factor that cancels in O / l)
+      const float cand = bm * sc2;
+      mn[t] = cand > m[t] + LAZY_LOG2 ? cand : m[t];
+      moved |= mn[t] > m[t];
+    }
+    if (__any(moved)) {  // wave-uniform: rare after the first key blocks
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float alpha = fast_exp2(m[t] - mn[t]);
+        l[t] *= alpha;
+        oacc[t][0] *= alpha;
+        oacc[t][1] *= alpha;
+        m[t] = mn[t];
+      }
+    }
+    bf16x8 pf[T][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const f32x2 mv = {-m[t], -m[t]};
+      f32x2 acc = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x2 v = {s[t][2 * i], s[t][2 * i + 1]};
+        v = __builtin_elementwise_fma(v, sc2v, mv);
+        v[0] = fast_exp2(v[0]);
+        v[1] = fast_exp2(v[1]);
+        acc += v;
+        s[t][2 * i] = v[0];
+        s[t][2 * i + 1] = v[1];
+      }
+      l[t] += acc[0] + acc[1];
+      pf[t][0] = pack8r(s[t], 0);
+      pf[t][1] = pack8r(s[t], 8);
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) oacc[t][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][ks], pf[t][ks], oacc[t][db], 0, 0, 0);
+      }
+  }
+}
+
+// one query row of O^T (this lane: d = 32 db + 8 g + 4 hi + e) -> bf16 out row.  The two half-lanes of a query trade 8-byte
+// pieces first so that each writes 16 contiguous bytes: 4 stores of 16 B per lane instead of 8 of 8 B.
+__device__ __forceinline__ void store_o_row(bf16* orow, const f32x16 (&o)[2], float inv, int hi, bool valid) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint32_t x[2], y[2];  // x: piece g = 2j, y: piece g = 2j + 1 of this lane
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const f32x2 vx = {o[db][8 * j + 2 * w] * inv, o[db][8 * j + 2 * w + 1] * inv};
+        const f32x2 vy = {o[db][8 * j + 4 + 2 * w] * inv, o[db][8 * j + 4 + 2 * w + 1] * inv};
+        const bf16x2 bx = __builtin_convertvector(vx, bf16x2), by = __builtin_convertvector(vy, bf16x2);
+        x[w] = __builtin_bit_cast(uint32_t, bx);
+        y[w] = __builtin_bit_cast(uint32_t, by);
+      }
+      // permlane32_swap(x, y): lanes < 32 end with (own x, partner's x), lanes >= 32 with (partner's y, own y)
+      uint32_t out[4];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x[w], y[w], false, false);
+        out[w] = r[0];
+        out[2 + w] = r[1];
+      }
+      if (valid) {
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        *(u32x4*)(orow + db * 32 + 16 * j + 8 * hi) = u32x4{out[0], out[1], out[2], out[3]};
+      }
+    }
+}
+
+// LDS-DMA of one 8-row piece from inline asm: the compiler does not see it, so it puts no s_waitcnt vmcnt(0) in front of LDS reads
+// it cannot prove disjoint (that would serialise the stream and the key loop); completion is counted by hand.  The dynamic segment
+// is the kernel's only LDS, so LDS addresses are offsets from smem.
+__device__ __forceinline__ void stage_piece_asm(const bf16* base, long sn, int N, int piece, unsigned img_off, int lane) {
+  const int row = piece * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ swz_key(row);
+  const unsigned voff = (unsigned)(min(row, N - 1) * (int)sn + c * 8) * 2u;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(img_off + piece * 1024);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(base), "s"(dst)
+               : "memory");
+}
+// this wave's pieces of key block kb of both images (K at LDS offset 0, V at img): pieces 4 kb + {wave, wave + nwaves, ..} < 4 kb + 4
+__device__ __forceinline__ void stage_block_asm(const bf16* kbase, const bf16* vbase, long sn, int N, int kb, unsigned img, int wave,
+                                                int nwaves, int lane) {
+  for (int j = wave; j < 4; j += nwaves) {
+    stage_piece_asm(kbase, sn, N, kb * 4 + j, 0, lane);
+    stage_piece_asm(vbase, sn, N, kb * 4 + j, img, lane);
+  }
+}
+
+// phase stamps of one workgroup (VTP_ATTN_TIMING=1: the launcher passes a buffer in p.delta and prints the cycle counts)
+#define ATTN_TSTAMP(i)                                                                            \
+  do {                                                                                            \
+    if (p.delta && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0)                               \
+      ((long long*)p.delta)[wave * 8 + (i)] = __builtin_readcyclecounter();                       \
+  } while (0)
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_res2_kernel(const AttnResArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + p.npad * 128;
+  float* part = (float*)(smem + 2 * p.npad * 128);  // [wave][column][half][34]: partial (m, l, O) of the split last tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, hi = lane >> 5;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const bf16* qb = p.q + (long)b * p.sb + h * 64;
+  const int ntiles = p.npad >> 5, nkb = ntiles, q0 = wave * 64;
+  ATTN_TSTAMP(0);
+  const bool split_last = (ntiles & 1) && ntiles > 1;  // the launcher guarantees N - 32 (ntiles - 1) <= RES_SPLIT_COLS then
+  const int qL = (ntiles - 1) * 32;
+  bf16x8 qf[2][4], qfl[1][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bf16* qr = qb + (long)min(q0 + 32 * t + (lane & 31), p.N - 1) * p.sn + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qr + ks * 16);
+  }
+  if (split_last) {
+    const bf16* qr = qb + (long)min(qL + (lane & 31), p.N - 1) * p.sn + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qfl[0][ks] = *(const bf16x8*)(qr + ks * 16);
+  }
+  // K / V stream in key-block order: the query fragments and blocks 0, 1 are waited for here (a wait the compiler models, so it
+  // adds none of its own later), the rest is issued behind them and lands while the key loop runs
+  const bf16* kbase = p.k + (long)b * p.sb + h * 64;
+  const bf16* vbase = p.v + (long)b * p.sb + h * 64;
+  const unsigned img = p.npad * 128;
+  stage_block_asm(kbase, vbase, p.sn, p.N, 0, img, wave, nwaves, lane);
+  if (nkb > 1) stage_block_asm(kbase, vbase, p.sn, p.N, 1, img, wave, nwaves, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  ATTN_TSTAMP(1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  ATTN_TSTAMP(2);
+  for (int kb = 2; kb < nkb; ++kb) stage_block_asm(kbase, vbase, p.sn, p.N, kb, img, wave, nwaves, lane);
+  const int stream_ops = 2 * ((4 - wave + nwaves - 1) / nwaves);  // this wave's DMA operations per key block
+  const float sc2 = p.scale * LOG2E_R;
+  const long srow0 = ((long)b * p.heads + h) * p.N;
+  {
+    f32x16 oacc[2][2];
+    float m[2], l[2];
+    const bool two = q0 + 32 < p.npad && !(split_last && q0 + 32 >= qL);
+    if (two) attn_key_loop<2>(Ks, Vs, qf, p.N, nkb, 0, 1, sc2, lane, oacc, m, l, stream_ops);
+    else {
+      f32x16 (&o1)[1][2] = *(f32x16(*)[1][2])&oacc;
+      attn_key_loop<1>(Ks, Vs, *(const bf16x8(*)[1][4])&qf, p.N, nkb, 0, 1, sc2, lane, o1, *(float(*)[1])&m, *(float(*)[1])&l,
+                       stream_ops);
+    }
+    ATTN_TSTAMP(3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !two) break;
+      const int qi = q0 + 32 * t + (lane & 31);
+      const float lt = both_halves_sum(l[t]);
+      const bool valid = qi < p.N;
+      store_o_row(p.out + (long)b * p.sbo + (long)min(qi, p.N - 1) * p.sno + h * 64, oacc[t], 1.f / lt, hi, valid);
+      if (valid && hi == 0 && p.lse) p.lse[srow0 + qi] = (m[t] + log2f(lt)) * LN2_R;
+    }
+  }
+  ATTN_TSTAMP(4);
+  if (!split_last) return;
+  // ---- the odd last tile: this wave's share of the key blocks, then the merge
+  const int cols = p.N - qL;  // valid queries of the tile
+  {
+    f32x16 oacc[1][2];
+    float m[1], l[1];
+    attn_key_loop<1>(Ks, Vs, qfl, p.N, nkb, wave, nwaves, sc2, lane, oacc, m, l);
+    const float lt = both_halves_sum(l[0]);
+    if ((lane & 31) < cols) {
+      float* dst = part + ((wave * cols + (lane & 31)) * 2 + hi) * 34;
+      dst[0] = m[0];
+      dst[1] = lt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dst[2 + r] = oacc[0][0][r];
+        dst[18 + r] = oacc[0][1][r];
+      }
+    }
+  }
+  ATTN_TSTAMP(5);
+  __syncthreads();
+  ATTN_TSTAMP(6);
+  if (wave != 0) return;
+  {
+    const int c = min(lane & 31, cols - 1);
+    float M = -INFINITY;
+    for (int w = 0; w < nwaves; ++w) M = fmaxf(M, part[((w * cols + c) * 2 + hi) * 34]);
+    f32x16 o[2];
+    zero16r(o[0]);
+    zero16r(o[1]);
+    float L = 0.f;
+    for (int w = 0; w < nwaves; ++w) {
+      const float* src = part + ((w * cols + c) * 2 + hi) * 34;
+      const float sc = fast_exp2(src[0] - M);
+      L += src[1] * sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] += src[2 + r] * sc;
+        o[1][r] += src[18 + r] * sc;
+      }
+    }
+    const int qi = qL + (lane & 31);
+    const bool valid = (lane & 31) < cols;
+    store_o_row(p.out + (long)b * p.sbo + (long)min(qi, p.N - 1) * p.sno + h * 64, o, 1.f / L, hi, valid);
+    if (valid && hi == 0 && p.lse) p.lse[srow0 + qi] = (M + log2f(L)) * LN2_R;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
@@ -395,7 +734,36 @@ int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, floa
   static bool attr = false;
   if (!attr) {
     set_lds(attn_fwd_res_kernel, 2 * RES_MAXN * 128);
+    set_lds(attn_fwd_res2_kernel, 2 * RES_MAXN * 128 + 5 * RES_SPLIT_COLS * 2 * 34 * 4);
     attr = true;
+  }
+  static const int v2 = getenv("VTP_ATTN_V2") ? atoi(getenv("VTP_ATTN_V2")) : 1;
+  {
+    const int ntiles = a.npad / 32, cols = N - 32 * (ntiles - 1);
+    const bool odd = (ntiles & 1) && ntiles > 1;
+    if (v2 && (!odd || cols <= RES_SPLIT_COLS)) {  // two query tiles per wave, single pass, odd last tile split over the key blocks
+      const int waves = std::max(1, ntiles / 2);
+      const int lds = 2 * a.npad * 128 + (odd ? waves * cols * 2 * 34 * 4 : 0);
+      static long long* tbuf = nullptr;
+      static const bool timing = getenv("VTP_ATTN_TIMING") != nullptr;
+      if (timing && !tbuf && hipMalloc((void**)&tbuf, 64 * 8) != hipSuccess) tbuf = nullptr;
+      if (timing) a.delta = (float*)tbuf;
+      hipLaunchKernelGGL(attn_fwd_res2_kernel, dim3(heads, B), dim3(64 * waves), lds, s, a);
+      if (timing && tbuf) {  // diagnosis only: synchronous
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, attn_fwd_res2_kernel, 64 * waves, lds);
+        fprintf(stderr, "[attn timing] workgroups per CU by the runtime's count: %d (lds %d B, %d waves)\n", occ, lds, waves);
+        long long hbuf[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hbuf, tbuf, sizeof hbuf, hipMemcpyDeviceToHost);
+        for (int w = 0; w < waves; ++w) {
+          fprintf(stderr, "[attn timing] wave %d:", w);
+          for (int i = 1; i < 7; ++i) fprintf(stderr, " t%d=%lld", i, hbuf[w * 8 + i] - hbuf[0]);
+          fprintf(stderr, "\n");
+        }
+      }
+      return check_launch("attn_fwd_resident2");
+    }
   }
   const int nw = a.npad / 32, wpb = res_waves_per_block(nw, heads * B);
   hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(heads, B, (nw + wpb - 1) / wpb), dim3(64 * wpb), 2 * a.npad * 128, s, a);

@@ -630,6 +630,19 @@ class Stack:
             yield r0, B, N, rope
             r0 += B * N
 
+    @staticmethod
+    def _attn_rows(segs):
+        """_rows with neighbouring segments of equal sequence length and the same RoPE tables merged into one batch (the clean
+        images and the global crops of a list forward: one attention launch instead of two, a better last round of workgroups)."""
+        out = []
+        for r0, B, N, rope in Stack._rows(segs):
+            if out and out[-1][2] == N and (out[-1][3] is rope or (out[-1][3] is not None and rope is not None
+                                                                 and out[-1][3][0] is rope[0] and out[-1][3][1] is rope[1])):
+                out[-1] = (out[-1][0], out[-1][1] + B, N, rope)
+            else:
+                out.append((r0, B, N, rope))
+        return out
+
     # x: f32 [M, D] input residual.  Returns the output residual (f32 [M, D]).
     def forward(self, ws: Workspace, x, B: int, N: int, rope, prefix_tokens: int, train: bool, segs=None):
         """`segs` = [(B_i, N_i, rope_i)]: several batches of different sequence length concatenated along the token-row
@@ -662,7 +675,7 @@ class Stack:
                 ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, M, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
             else:
                 ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
-            for r0, Bs, Ns, rp in self._rows(segs):
+            for r0, Bs, Ns, rp in self._attn_rows(segs):
                 q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
                 if rp is not None and rope_plan is None:
                     ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
@@ -735,7 +748,7 @@ class Stack:
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
             linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o, bias_grad_done=b.proj.gb is not None,
                        ls=(b.ls1, b.gls1) if b.ls1 is not None else None)
-            for r0, Bs, Ns, rp in self._rows(segs):
+            for r0, Bs, Ns, rp in self._attn_rows(segs):
                 r1 = r0 + Bs * Ns
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
                 # dq / dk come back as gradients w.r.t. the un-rotated q, k (inverse RoPE fused into the attention backward)
