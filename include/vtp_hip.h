@@ -183,6 +183,10 @@ int vtp_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n
 /* same, hyper-parameters read from DEVICE memory: hyper[8] = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t,
  * sqrt(1-beta2^t), grad_scale} -- lets a captured hipGraph of the training step replay with per-step values. */
 int vtp_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const float* hyper, void* stream);
+/* the same with a weight-decay exemption table: nodecay4[i] != 0 exempts elements [4i, 4i + 4) (one flag per float4 -- parameters are
+ * padded to 4 elements in the flat buffer): biases / norm gains / tokens / logit scale follow the usual AdamW recipe */
+int vtp_adamw_dev_masked(float* p, const float* g, float* m, float* v, void* p_bf16, const void* nodecay4, long n, const float* hyper,
+                         void* stream);
 /* dst[i] (+)= sum_{s<S} slabs[s*stride + i], f32 (split-K partials -> gradient buffer). */
 int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n, int accumulate, void* stream);
 /* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
@@ -258,6 +262,8 @@ int vtp_weight_norm_bwd(const float* dW, const float* v, const float* g, const f
                         void* stream);
 /* teacher targets: probs bf16 [T,K] = softmax((logits - center) * inv_temp) row-wise (center f32 [K] or NULL). */
 int vtp_softmax_center(const void* logits, const float* center, float inv_temp, void* probs, int T, int K, void* stream);
+/* the same with the inverse temperature read from device memory (teacher-temperature schedules under hipGraph replay) */
+int vtp_softmax_center_dev(const void* logits, const float* center, const float* inv_temp, void* probs, int T, int K, void* stream);
 /* student cross-entropy (DINO cls / iBOT patch loss; OUR spec, DINOv2 convention): for student row r with teacher target rows
  * t_idx0[r], t_idx1[r] (-1 = none; t_idx0 < 0 or row_weight 0 = padding row):
  *   loss_sum += w_r * sum_targets( -sum_k p_t[k] * log_softmax(s_r * inv_temp)[k] ),

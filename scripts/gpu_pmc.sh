@@ -5,7 +5,7 @@ R=$PWD
 rm -rf $R/gpurun_out/pmc; mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graphs > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-lpips-run --no-graphs > $R/gpurun_out/pmc_$c.log 2>&1
   echo "pmc $c rc=$?"
 done
 cd $R

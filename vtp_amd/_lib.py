@@ -32,6 +32,7 @@ SIGNATURES = {
     "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "vtp_adamw": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "vtp_adamw_dev": [_P, _P, _P, _P, _P, _L, _P, _P],
+    "vtp_adamw_dev_masked": [_P, _P, _P, _P, _P, _P, _L, _P, _P],
     "vtp_reduce_slabs": [_P, _L, _I, _P, _L, _I, _P],
     "vtp_gemm_splits": [_I, _I],
     "vtp_gemm_tn_splits": [_I, _I, _I],
@@ -53,6 +54,7 @@ SIGNATURES = {
     "vtp_weight_norm_prep": [_P, _P, _P, _P, _P, _I, _I, _P],
     "vtp_weight_norm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vtp_softmax_center": [_P, _P, _F, _P, _I, _I, _P],
+    "vtp_softmax_center_dev": [_P, _P, _P, _P, _I, _I, _P],
     "vtp_dino_ce": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     "vtp_center_ema": [_P, _P, _F, _P, _F, _I, _P],
     "vtp_conv3x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

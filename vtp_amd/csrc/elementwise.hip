@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16* __restrict__ pb, long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt, float gs,
-                                                    const float* __restrict__ hyper) {
+                                                    const float* __restrict__ hyper, const uint8_t* __restrict__ nodecay4 = nullptr) {
   if (hyper) {  // device-resident hyper-parameters: a captured hipGraph replays with fresh values every step
     lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; bc1 = hyper[5]; bc2_sqrt = hyper[6]; gs = hyper[7];
   }
@@ -409,10 +409,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
     f32x4 pv = *(const f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i);
     f32x4 mv = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
+    const float keep = (nodecay4 && nodecay4[i]) ? 1.f : 1.f - lr * wd;  // parameters are padded to 4 elements: one flag per float4
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gg = gv[e] * gs;
-      pv[e] *= (1.f - lr * wd);
+      pv[e] *= keep;
       mv[e] = b1 * mv[e] + (1.f - b1) * gg;
       vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
@@ -642,6 +643,14 @@ extern "C" int vtp_adamw_dev(float* p, const float* g, float* m, float* v, void*
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, 0.f,
                      0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, hyper);
   return check_launch("adamw_dev");
+}
+
+extern "C" int vtp_adamw_dev_masked(float* p, const float* g, float* m, float* v, void* p_bf16, const void* nodecay4, long n,
+                                    const float* hyper, void* stream) {
+  VTP_REQUIRE(p && g && m && v && hyper && nodecay4 && n > 0 && n % 4 == 0, "vtp_adamw_dev_masked: bad argument (n %% 4 == 0)");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16, n, 0.f,
+                     0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, hyper, (const uint8_t*)nodecay4);
+  return check_launch("adamw_dev_masked");
 }
 
 extern "C" int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n, int accumulate, void* stream) {

@@ -69,18 +69,29 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   const int tiles_m = (p.M + 255) >> 8;
   const int tiles_n = (p.N + 255) >> 8;
   const int ntiles = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  const int n_my = (ntiles - (int)blockIdx.x + G - 1) / G;
+  // split-K launches arrive as ONE flat grid of ntiles x splits workgroups (bit 2 of xcd_swizzle): workgroups are dealt to the 8
+  // XCDs round-robin, and XCD x takes a contiguous chunk of the (split-major) list -- so the tiles that stream the same K slice of
+  // A / B sit behind ONE L2 and that slice is fetched from HBM once, not once per XCD
+  const bool flat = (p.xcd_swizzle & 4) != 0;
+  int bx = blockIdx.x, zslice = blockIdx.z;
+  if (flat) {
+    const int W = gridDim.x, q = W >> 3, r = W & 7, x = bx & 7;
+    const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bx >> 3);
+    zslice = c / ntiles;
+    bx = c - zslice * ntiles;
+  }
+  const int G = flat ? ntiles : gridDim.x;
+  const int n_my = (ntiles - bx + G - 1) / G;
   auto tile_origin = [&](int i, int& m0, int& n0) {
-    int wg = blockIdx.x + i * G;
-    if (p.xcd_swizzle & 1) {  // bijective on [0, ntiles): XCD x owns a contiguous chunk of the tile list
+    int wg = bx + i * G;
+    if ((p.xcd_swizzle & 1) && !flat) {  // bijective on [0, ntiles): XCD x owns a contiguous chunk of the tile list
       const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
       wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
     }
     n0 = (wg % tiles_n) << 8;
     m0 = (wg / tiles_n) << 8;
   };
-  const int kbeg = blockIdx.z * p.k_split;
+  const int kbeg = zslice * p.k_split;
   const int kend = min(p.K, kbeg + p.k_split);
   const int nk = (kend - kbeg + 63) >> 6;
   const int H = n_my * nk * 4;  // half-tiles this workgroup streams
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       }
     }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
-    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane);
+    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
     zero_acc();
   }
 }
@@ -373,6 +384,13 @@ static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
     if (cus < 8) cus = 8;
   }
   const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  static const bool flat_ok = !(getenv("VTP_GEMM_FLAT_SPLIT") && atoi(getenv("VTP_GEMM_FLAT_SPLIT")) == 0);
+  if (splits > 1 && flat_ok) {
+    GemmArgs f = a;
+    f.xcd_swizzle |= 4;
+    hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(512), P8_LDS, s, f);
+    return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
+  }
   dim3 grid(splits == 1 && ntiles > cus ? cus : ntiles, 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS, s, a);
   return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");

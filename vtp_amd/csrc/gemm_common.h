@@ -71,7 +71,7 @@ __device__ __forceinline__ bool gemm_epilogue_uses_lds(const GemmArgs& p) {
 // reg: this wave's private LDS staging region of REGION bytes (or null: direct stores).
 template <int EPI, bool TRANS, int WTM, int WTN, int REGION>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[WTN / 32][WTM / 32], char* reg, int m0, int n0,
-                                              int wm, int wn, int lane) {
+                                              int wm, int wn, int lane, int zslice = blockIdx.z) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   const int hi = lane >> 5;
   // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
@@ -325,7 +325,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           } else if constexpr (EPI == EPI_F32_SLAB) {
             // split-K partial: slice z writes its own [rows, ldc] slab with plain 16-B stores (no atomics);
             // vtp_reduce_slabs sums the slabs afterwards.  slab stride (in float4 units) travels in ldc2.
-            *(f32x4*)((float*)p.C + (size_t)blockIdx.z * (size_t)p.ldc2 * 4 + (size_t)mc * p.ldc + n) = v;
+            *(f32x4*)((float*)p.C + (size_t)zslice * (size_t)p.ldc2 * 4 + (size_t)mc * p.ldc + n) = v;
           } else {
             if (p.bias) {
               f32x4 b = *(const f32x4*)(p.bias + n);

@@ -125,8 +125,10 @@ __device__ __forceinline__ void row_lse(const bf16* __restrict__ row, const floa
 
 // teacher targets: probs[r, :] = softmax((logits[r, :] - center) * inv_temp)   (bf16 out)
 __global__ __launch_bounds__(256) void softmax_center_kernel(const bf16* __restrict__ logits, const float* __restrict__ center,
-                                                             float inv_temp, bf16* __restrict__ probs, int K) {
+                                                             float inv_temp, bf16* __restrict__ probs, int K,
+                                                             const float* __restrict__ inv_temp_dev) {
   __shared__ float red[8];
+  if (inv_temp_dev) inv_temp = *inv_temp_dev;  // device-resident temperature: a captured hipGraph follows a schedule
   const bf16* row = logits + (long)blockIdx.x * K;
   float mx, se;
   row_lse(row, center, inv_temp, K, red, mx, se);
@@ -143,8 +145,10 @@ __global__ __launch_bounds__(256) void softmax_center_kernel(const bf16* __restr
 // register-resident variant for K <= 65536: 1024 threads hold the whole centred, scaled row (<= 64 values per lane), so logits
 // and the f32 centre are each read ONCE per row (the three-pass kernel above re-reads 128 KB + 256 KB per pass at K = 65536)
 __global__ __launch_bounds__(1024) void softmax_center_reg_kernel(const bf16* __restrict__ logits, const float* __restrict__ center,
-                                                                  float inv_temp, bf16* __restrict__ probs, int K) {
+                                                                  float inv_temp, bf16* __restrict__ probs, int K,
+                                                                  const float* __restrict__ inv_temp_dev) {
   __shared__ float red[32];
+  if (inv_temp_dev) inv_temp = *inv_temp_dev;
   const bf16* row = logits + (long)blockIdx.x * K;
   float z[8][8];
   float mx = -INFINITY;
@@ -297,16 +301,27 @@ extern "C" int vtp_weight_norm_bwd(const float* dW, const float* v, const float*
   return check_launch("weight_norm_bwd");
 }
 
+static int launch_softmax_center(const void* logits, const float* center, float inv_temp, const float* inv_temp_dev, void* probs, int T,
+                                 int K, void* stream) {
+  if (K <= 65536 && K >= 8192)
+    hipLaunchKernelGGL(softmax_center_reg_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, center,
+                       inv_temp, (bf16*)probs, K, inv_temp_dev);
+  else
+    hipLaunchKernelGGL(softmax_center_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, center, inv_temp,
+                       (bf16*)probs, K, inv_temp_dev);
+  return check_launch("softmax_center");
+}
+
 extern "C" int vtp_softmax_center(const void* logits, const float* center, float inv_temp, void* probs, int T, int K,
                                   void* stream) {
   VTP_REQUIRE(logits && probs && T > 0 && K > 0 && K % 8 == 0, "vtp_softmax_center: bad argument (K %% 8 == 0)");
-  if (K <= 65536 && K >= 8192)
-    hipLaunchKernelGGL(softmax_center_reg_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, center,
-                       inv_temp, (bf16*)probs, K);
-  else
-    hipLaunchKernelGGL(softmax_center_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, center, inv_temp,
-                       (bf16*)probs, K);
-  return check_launch("softmax_center");
+  return launch_softmax_center(logits, center, inv_temp, nullptr, probs, T, K, stream);
+}
+
+extern "C" int vtp_softmax_center_dev(const void* logits, const float* center, const float* inv_temp, void* probs, int T, int K,
+                                      void* stream) {
+  VTP_REQUIRE(logits && probs && inv_temp && T > 0 && K > 0 && K % 8 == 0, "vtp_softmax_center_dev: bad argument (K %% 8 == 0)");
+  return launch_softmax_center(logits, center, 0.f, inv_temp, probs, T, K, stream);
 }
 
 extern "C" int vtp_dino_ce(const void* student_logits, const void* teacher_probs, const int* t_idx0, const int* t_idx1,

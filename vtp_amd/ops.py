@@ -133,8 +133,13 @@ def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, grad_scale=1.0
                                  _s()), "vtp_adamw")
 
 
-def adamw_dev(p, g, m, v, p_bf16, n, hyper):
-    _lib.check(_lib_().vtp_adamw_dev(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _s()), "vtp_adamw_dev")
+def adamw_dev(p, g, m, v, p_bf16, n, hyper, nodecay4=None):
+    """nodecay4: uint8 [n / 4], non-zero = the four elements are exempt from weight decay"""
+    if nodecay4 is None:
+        _lib.check(_lib_().vtp_adamw_dev(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(hyper), _s()), "vtp_adamw_dev")
+    else:
+        _lib.check(_lib_().vtp_adamw_dev_masked(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(nodecay4), n, _p(hyper), _s()),
+                   "vtp_adamw_dev_masked")
 
 
 def gemm_tn(a, b, c, *, M, N, K, lda, ldb, ldc, ldc2=0, resid=None, epi=EPI_F32, a_remap=(0, 0), b_remap=(0, 0),
@@ -257,7 +262,11 @@ def weight_norm_bwd(dW, v, g, inv_norm, dv, dg, K, C):
 
 
 def softmax_center(logits, center, inv_temp, probs, T, K):
-    _lib.check(_lib_().vtp_softmax_center(_p(logits), _p(center), inv_temp, _p(probs), T, K, _s()), "vtp_softmax_center")
+    """inv_temp: float, or a device f32 tensor (read by the kernel: graph-replay safe schedules)"""
+    if isinstance(inv_temp, torch.Tensor):
+        _lib.check(_lib_().vtp_softmax_center_dev(_p(logits), _p(center), _p(inv_temp), _p(probs), T, K, _s()), "vtp_softmax_center_dev")
+    else:
+        _lib.check(_lib_().vtp_softmax_center(_p(logits), _p(center), inv_temp, _p(probs), T, K, _s()), "vtp_softmax_center")
 
 
 def dino_ce(s_logits, t_probs, t0, t1, w, inv_temp, loss_sum, d_logits, T, K):

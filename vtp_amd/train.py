@@ -147,6 +147,13 @@ def param_ranges(offsets, prefixes: Sequence[str]) -> List[Tuple[int, int]]:
     return merge_ranges(r)
 
 
+NO_DECAY_NAMES = ("logit_scale", "logit_bias", "cls_token", "mask_token", "positional_embedding", "storage_tokens")
+
+
+def default_no_decay(name: str, shape: tuple) -> bool:
+    return len(shape) < 2 or name.rsplit(".", 1)[-1] in NO_DECAY_NAMES
+
+
 CLIP_PREFIXES = ("visual_proj.", "text_transformer.", "token_embedding.", "positional_embedding", "ln_final.",
                  "text_projection", "logit_scale", "logit_bias")
 
@@ -161,7 +168,7 @@ class VTPTrainer:
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
                  lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
                  drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3,
-                 shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32"):
+                 shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32", no_decay="default"):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
@@ -203,11 +210,23 @@ class VTPTrainer:
             self.center_stats = torch.zeros(2 * K + 8, dtype=F32, device=st.device)  # [sum_dino | sum_ibot | n_masked, pad]
             self.ssl_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
             self.koleo_loss_sum = torch.zeros(1, dtype=F32, device=st.device)
-            self.momentum_dev = torch.zeros(4, dtype=F32, device=st.device)
         self._ssl_static = {}
         self.ssl_bucket = int(os.environ.get("VTP_SSL_BUCKET", "512"))  # masked-token rows are padded to a multiple of this
         self.m = torch.zeros_like(st.flat_p)
         self.v = torch.zeros_like(st.flat_p)
+        # weight-decay exemptions (the usual AdamW recipe of OpenCLIP / DINOv2 training loops; the reference ships no optimizer):
+        # no_decay = "default" (biases, norm / LayerScale gains, tokens, positional embeddings, logit scale / bias -- every
+        # parameter with ndim < 2 or one of the named tensors), None (decay everything) or a predicate (name, shape) -> bool.
+        # One flag per float4 of the flat buffer (parameters are padded to 4 elements).
+        if no_decay == "default":
+            no_decay = default_no_decay
+        self.nodecay4 = None
+        if no_decay is not None:
+            flags = torch.zeros(st.numel // 4, dtype=torch.uint8)
+            for name, (o, k) in st.offsets.items():
+                if no_decay(name, tuple(st.params[name].shape)):
+                    flags[o // 4:(o + (k + 3) // 4 * 4) // 4] = 1
+            self.nodecay4 = flags.to(st.device)
         self.step_no = 0
         self.loss_sum = torch.zeros(1, dtype=F32, device=st.device)       # L1 numerator
         self.clip_loss_sum = torch.zeros(1, dtype=F32, device=st.device)  # contrastive loss (already a mean)
@@ -228,7 +247,9 @@ class VTPTrainer:
         self.bucket_blocks = bucket_blocks
         self._bucket_plan = self._plan_buckets()
         # hyper-parameters live in device memory so that captured hipGraphs replay with per-step values
-        self.hyper = torch.zeros(8, dtype=F32, device=st.device)
+        self.hyper = torch.zeros(16, dtype=F32, device=st.device)  # [lr b1 b2 eps wd bc1 sqrt(bc2) 1/world | 1/teacher_temp ema_m ...]
+        self.momentum_dev = self.hyper[9:10]  # EMA teacher momentum of this step
+        self._hyper_ring = None
         self.use_graphs = use_graphs
         self._graphs = {}
         if self.text is not None and (model.config.vision_clip_feat != "cls" or not model.config.vision_bottleneck_ae_only):
@@ -320,8 +341,9 @@ class VTPTrainer:
         if self.centering == "sinkhorn_knopp":
             yield from self._sinkhorn_targets(ws, t_logits, probs, P, B2, Tm, K)
         else:
-            ops.softmax_center(t_logits, self.center_dino, 1.0 / self.teacher_temp, probs, B2, K)
-            ops.softmax_center(t_logits[B2:], self.center_ibot, 1.0 / self.teacher_temp, probs[B2:], Tm, K)
+            inv_tt = self.hyper[8:9]  # 1 / teacher_temp of THIS step (device memory: the usual warm-up schedule replays correctly)
+            ops.softmax_center(t_logits, self.center_dino, inv_tt, probs, B2, K)
+            ops.softmax_center(t_logits[B2:], self.center_ibot, inv_tt, probs[B2:], Tm, K)
             # centre statistics of this batch (teacher outputs), summed over ranks, then EMA
             stats = self.center_stats
             stats.zero_()
@@ -577,14 +599,16 @@ class VTPTrainer:
                 if n > 0:
                     if rec.g32 is not rec.g_out:
                         rec.g32.copy_(rec.g_out)
-                    ops.adamw_dev(st.flat_p[rec.a:rec.b], rec.g32, self.m[rec.a:rec.b], self.v[rec.a:rec.b], None, n, self.hyper)
+                    ops.adamw_dev(st.flat_p[rec.a:rec.b], rec.g32, self.m[rec.a:rec.b], self.v[rec.a:rec.b], None, n, self.hyper,
+                                  None if self.nodecay4 is None else self.nodecay4[rec.a // 4:rec.b // 4])
                     rec.p_send[:n].copy_(st.flat_p[rec.a:rec.b])
             yield lambda: self.bucketer.all_gather_params(st.flat_p, recs)
             for rec in recs:
                 st.flat_p[rec.lo:rec.hi].copy_(rec.p_recv[:rec.hi - rec.lo])
         else:
             for lo, hi in ranges:
-                ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper)
+                ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper,
+                              None if self.nodecay4 is None else self.nodecay4[lo // 4:hi // 4])
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
@@ -667,12 +691,23 @@ class VTPTrainer:
         self.step_no += 1
         b1, b2 = self.betas
         vals = [self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.step_no, (1.0 - b2 ** self.step_no) ** 0.5,
-                1.0 / self.world]
-        # a FRESH pinned staging tensor per step: the host may run several steps ahead of the GPU (graph replay), and the
-        # caching host allocator only recycles a pinned block after the async copy that reads it has completed
-        self.hyper.copy_(torch.tensor(vals, dtype=torch.float32).pin_memory(), non_blocking=True)
+                1.0 / self.world, 1.0 / self.teacher_temp, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
         if self.ssl_head is not None:
-            self.momentum_dev.fill_(float(self.teacher_momentum))
+            vals[9] = float(self.teacher_momentum)
+        # a ring of pinned staging rows: the host may run several steps ahead of the GPU (graph replay), so a row is rewritten
+        # only after the async copy that read it has completed (its event); no per-step allocation
+        if self._hyper_ring is None:
+            self._hyper_ring = (torch.zeros(8, 16, dtype=torch.float32).pin_memory(), [None] * 8)
+        ring, events = self._hyper_ring
+        slot = self.step_no % ring.shape[0]
+        if events[slot] is not None:
+            events[slot].synchronize()
+        ring[slot].copy_(torch.tensor(vals, dtype=torch.float32))
+        self.hyper.copy_(ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events[slot] = ev
+
 
     def _handle(self, ev):
         if callable(ev):
@@ -752,7 +787,12 @@ class VTPTrainer:
         if ssl is not None:
             pl = ssl["plan"]
             skey = (tuple(ssl["global"].shape), tuple(ssl["local"].shape), pl["Ts"])  # Ts: padded (bucketed) row count
-        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate > 0, self.decoder_drop_rate > 0)
+        # host-side scalars that a captured segment bakes in (kernel arguments): a change re-captures instead of replaying stale
+        # values; lr / betas / weight decay / teacher temperature / EMA momentum live in device memory and are not part of the key
+        baked = (self.clip_weight, self.rec_weight, self.perceptual_weight, self.student_temp, self.koleo_weight, self.centering,
+                 self.teacher_temp if self.centering == "sinkhorn_knopp" else None, self.center_momentum)
+        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate > 0, self.decoder_drop_rate > 0,
+               baked)
         plan = self._graphs.get(key)
         if plan is None:
             st = self.store
