@@ -41,12 +41,20 @@ PEAK_BF16_TFLOPS = 2500.0
 
 _SMALL = dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_embed_dim=384, text_depth=12,
               text_num_heads=6, decoder_embed_dim=384, decoder_depth=12, decoder_num_heads=6)
+_LARGE = dict(vision_embed_dim=1024, vision_depth=24, vision_num_heads=16, text_embed_dim=1024, text_depth=24,
+              text_num_heads=16, decoder_embed_dim=1024, decoder_depth=24, decoder_num_heads=16)
+PEAK_FP8_TFLOPS = 5000.0
+# forward-only workloads (no optimizer step): BASELINE config 5
+FORWARD_WORKLOADS = {
+    "vtp_large_fp8_fwd": (_LARGE, 64, 256),   # VTP-L encode -> decode, fp8 (e4m3) MFMA GEMMs, 64 img/GPU
+}
 WORKLOADS = {
     # name: (config kwargs, per-GPU batch, resolution, objectives)
     "vtp_base_full": (dict(), 32, 256, ("rec", "clip", "ssl")),  # BASELINE config 3: contrastive + SSL + recon
     "vtp_base_rec_clip": (dict(), 32, 256, ("rec", "clip")),
     "vtp_base_rec": (dict(), 32, 256, ("rec",)),
     "vtp_small_rec": (_SMALL, 64, 256, ("rec",)),               # BASELINE config 2
+    "vtp_large_full_512": (_LARGE, 16, 512, ("rec", "clip", "ssl")),  # BASELINE config 4: long sequences (N = 1025)
 }
 
 
@@ -172,12 +180,103 @@ def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=14.0):
             "ms_per_step_fp32": round(t32 * 1e3, 1), "threads": n_thr}
 
 
+def bench_forward(args, world, rank, dev):
+    """BASELINE config 5: VTP-L encode -> decode throughput with the linear maps on the fp8 (e4m3) MFMA path; the bf16 path of the
+    same model is timed beside it and the output difference is reported (random-init weights, synthetic images).  Independent
+    images: ranks are replicas with their own batch, no data-path collective."""
+    from vtp_amd import VTPConfig, VTPModel, ops
+    cfg_kw, B, res = FORWARD_WORKLOADS[args.workload]
+    B = args.batch or B
+    torch.manual_seed(0)
+    model = VTPModel(VTPConfig(**cfg_kw)).to(dev).eval()
+    img = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        lat = model.get_reconstruction_latents(img)
+        return lat, model.get_latents_decoded_images(lat)
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            one_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one_step()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t)
+        return el, out
+
+    with torch.no_grad():
+        el_bf16, (lat_b, rec_b) = timed(max(2, args.steps // 2), max(1, args.warmup // 2))
+        n_bf16 = max(2, args.steps // 2)
+        model.enable_fp8_forward(img[: min(B, 16)])
+        el, (lat_8, rec_8) = timed(args.steps, args.warmup)
+        rec_same = model.get_latents_decoded_images(lat_b)
+        rel = lambda a, b: float((a - b).norm() / b.norm())
+        err = {"latents_rel": round(rel(lat_8, lat_b), 5), "decoder_rel_same_latents": round(rel(rec_same, rec_b), 5),
+               "end_to_end_rel": round(rel(rec_8, rec_b), 5)}
+        # roofline of the dominant kernel: HIP events around every fp8 GEMM launch of one extra pass (rank 0)
+        recs, orig = [], ops.gemm_nt_fp8
+
+        def probe(a8, b8, c, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(a8, b8, c, **kw)
+            e1.record()
+            recs.append((2.0 * kw["M"] * kw["N"] * kw["K"], e0, e1))
+
+        ops.gemm_nt_fp8 = probe
+        import vtp_amd.engine as eng
+        try:
+            one_step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_nt_fp8 = orig
+    c = model.config
+    hw = (res // 16) ** 2
+    from vtp_amd.config import swiglu_hidden
+    enc = vit_fwd_gflop(c.vision_embed_dim, swiglu_hidden(c.vision_embed_dim), c.vision_depth, hw + 1, hw, True)
+    dec = vit_fwd_gflop(c.decoder_embed_dim, swiglu_hidden(c.decoder_embed_dim), c.decoder_depth, hw, hw, False)
+    ips = world * B * args.steps / el
+    fl = sum(r[0] for r in recs)
+    ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+    ach = fl / (ms * 1e-3) / 1e12
+    out = {"metric": "images/sec/node VTP-L f16d64 fp8 forward encode->decode 256x256", "value": round(ips, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp8 e4m3 GEMM operands (per-tensor scales), fp32 accumulation, bf16 attention / fp32 residual", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: get_reconstruction_latents + get_latents_decoded_images of VTP-L (1024/24/16 trunk and "
+                                  f"pixel decoder), {B} img/GPU @ {res}x{res}, random-init weights, activation scales calibrated on 16 images",
+                      "per_gpu_batch": B, "global_batch": world * B, "resolution": res, "parallelism": f"dp{world} (replicas)",
+                      "fwd_gflop_per_image": round(enc + dec, 1)},
+           "bf16_path": {"value": round(world * B * n_bf16 / el_bf16, 2), "unit": "images/sec", "ms_per_step": round(el_bf16 / n_bf16 * 1e3, 3)},
+           "fp8_vs_bf16": err,
+           "step_tflops_per_gpu": round(ips / world * (enc + dec) / 1e3, 1)}
+    if rank == 0:
+        out["roofline"] = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<.., VAR=8> (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 x e4m3)",
+                           "achieved": round(ach, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP8_TFLOPS, 4),
+                           "traffic": None, "launches_per_step": len(recs), "gemm_ms_per_step": round(ms, 3)}
+        out["cpu_baseline"] = None  # reported on the default workload (the reference has no fp8 path)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS) + sorted(FORWARD_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -227,6 +326,8 @@ def main():
                   file=sys.stderr, flush=True)
 
     from vtp_amd import VTP, VTPConfig, VTPModel, VTPTrainer, ops
+    if args.workload in FORWARD_WORKLOADS:
+        return bench_forward(args, world, rank, dev)
     cfg_kw, B, res, objectives = WORKLOADS[args.workload]
     clip, do_ssl = "clip" in objectives, "ssl" in objectives
     B = args.batch or B

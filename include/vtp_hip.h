@@ -238,6 +238,23 @@ int vtp_koleo(const float* xn, int* nn_scratch, float* d_xn, float* loss_sum, in
 int vtp_sinkhorn_knopp(const void* logits, float inv_temp, void* probs, float* u, float* v, float* scratch, int T, int K, float count,
                        const float* count_dev, const int* n_rows_dev, int n_iters, int phase, void* stream);
 
+/* ---- fp8 forward path (BASELINE config 5: VTP-L encode -> decode with fp8 MFMA; fp8.hip, gemm8p.hip) --------
+ * e4m3 = the OCP fp8 format of gfx950, per-tensor scales:  q = e4m3(clamp(x * scale, -448, 448)).
+ * vtp_quantize_e4m3: src bf16 (src_is_f32 = 0) or f32 [n] -> dst bytes [n]; scale from device memory (scale_dev) or the argument.
+ * vtp_amax: amax[0] = max(amax[0], max |src|)  (calibration of the scales).   vtp_dequantize_e4m3: bytes -> f32 * inv_scale.
+ * vtp_gemm_nt_fp8: C[M,N] = alpha * A8[M,K] B8[N,K]^T (+ bias, + residual | SwiGLU), epilogues VTP_EPI_BF16 / F32 / SWIGLU as
+ *   in vtp_gemm_nt, alpha = 1 / (scale_A * scale_B); K, lda, ldb in fp8 elements, multiples of 16; rope_pos / rope_sin / rope_cos /
+ *   rope_cols (or nulls / 0): apply_rope fused into the bf16 epilogue exactly as in vtp_gemm_qkv_rope. */
+/* norm_fwd with the quantisation fused: y8[M, D] = e4m3(bf16(norm(x)) * q_scale[0]) (q_scale in device memory) */
+int vtp_norm_fwd_e4m3(const float* x, const float* w, const float* b, void* y8, const float* q_scale, float* stats, int M, int D,
+                      float eps, int kind, void* stream);
+int vtp_quantize_e4m3(const void* src, int src_is_f32, void* dst, long n, const float* scale_dev, float scale, void* stream);
+int vtp_amax(const void* src, int src_is_f32, long n, float* amax, void* stream);
+int vtp_dequantize_e4m3(const void* src, float* dst, long n, float inv_scale, void* stream);
+int vtp_gemm_nt_fp8(const void* A8, int lda, const void* B8, int ldb, void* C, int ldc, void* C2, int ldc2, const float* bias,
+                    const float* resid, int M, int N, int K, int epilogue, float alpha, const int* rope_pos, const void* rope_sin,
+                    const void* rope_cos, int rope_cols, void* stream);
+
 /* ---- tokenizer boundary (tokenizer.hip): the byte-image ends of generation/tokenizer/vtp_tokenizer.py --------
  * vtp_u8_to_images: ToTensor + Normalize(mean, std) (+ horizontal flip) of img_transform (vtp_tokenizer.py:74-81):
  *   img[b,c,y,x] = (float(u8[b,y,xs,c]) / 255 - mean[c]) / std[c], xs = flip ? W-1-x : x.   u8 NHWC -> f32 NCHW, W % 4 == 0.

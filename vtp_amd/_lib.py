@@ -45,6 +45,11 @@ SIGNATURES = {
     "vtp_layerscale_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vtp_scaled_transpose": [_P, _P, _P, _I, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
+    "vtp_norm_fwd_e4m3": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "vtp_quantize_e4m3": [_P, _I, _P, _L, _P, _F, _P],
+    "vtp_amax": [_P, _I, _L, _P, _P],
+    "vtp_dequantize_e4m3": [_P, _P, _L, _F, _P],
+    "vtp_gemm_nt_fp8": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P],
     "vtp_u8_to_images": [_P, _P, _L, _I, _I, _P, _P, _I, _P],
     "vtp_images_to_u8": [_P, _P, _L, _I, _I, _P, _P, _P],
     "vtp_latent_channel_stats": [_P, _P, _L, _I, _I, _P],

@@ -542,6 +542,37 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   return VTP_OK;
 }
 
+// fp8 (e4m3, OCP) forward GEMM (BASELINE config 5): C = alpha * (A8 B8^T) (+ bias, + residual / SwiGLU), A8 [M, K] and B8 [N, K]
+// row-major bytes, alpha = 1 / (scale_a * scale_b) of the per-tensor quantisation.  Runs the 256 x 256 8-phase kernel with the
+// 32x32x64 f8f6f4 MFMA; K and the leading dimensions are in fp8 elements and multiples of 16 here.
+namespace vtp {
+int launch_gemm8p_nt_fp8(const GemmArgs& a, int epi, hipStream_t s);
+}
+extern "C" int vtp_gemm_nt_fp8(const void* A8, int lda, const void* B8, int ldb, void* C, int ldc, void* C2, int ldc2,
+                               const float* bias, const float* resid, int M, int N, int K, int epilogue, float alpha,
+                               const int* rope_pos, const void* rope_sin, const void* rope_cos, int rope_cols, void* stream) {
+  VTP_REQUIRE(A8 && B8 && C, "vtp_gemm_nt_fp8: null operand");
+  VTP_REQUIRE(!rope_pos || (epilogue == VTP_EPI_BF16 && rope_sin && rope_cos && rope_cols % 128 == 0 && rope_cols <= N && N % 8 == 0 &&
+                            ldc % 8 == 0), "vtp_gemm_nt_fp8: fused RoPE needs the bf16 epilogue, both tables and rope_cols %% 128 == 0");
+  VTP_REQUIRE(M > 0 && N > 0 && K > 0, "vtp_gemm_nt_fp8: bad shape M=%d N=%d K=%d", M, N, K);
+  VTP_REQUIRE(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0, "vtp_gemm_nt_fp8: K, lda, ldb must be multiples of 16 (16-B rows)");
+  VTP_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "vtp_gemm_nt_fp8: N and ldc must be multiples of 4");
+  VTP_REQUIRE(((uintptr_t)A8 % 16 == 0) && ((uintptr_t)B8 % 16 == 0) && ((uintptr_t)C % 16 == 0), "vtp_gemm_nt_fp8: operands must be 16-B aligned");
+  VTP_REQUIRE(epilogue == VTP_EPI_BF16 || epilogue == VTP_EPI_F32 || epilogue == VTP_EPI_SWIGLU, "vtp_gemm_nt_fp8: forward epilogues only");
+  VTP_REQUIRE(epilogue != VTP_EPI_SWIGLU || (N % 16 == 0 && bias), "vtp_gemm_nt_fp8: SwiGLU epilogue needs interleaved N %% 16 == 0 and a bias");
+  GemmArgs a{};
+  a.A = (const bf16*)A8; a.B = (const bf16*)B8; a.C = C; a.C2 = C2; a.bias = bias; a.resid = resid;
+  a.M = M; a.N = N; a.K = K / 2; a.lda = lda / 2; a.ldb = ldb / 2; a.ldc = ldc; a.ldc2 = ldc2;  // 2-byte units for the staging side
+  a.alpha = alpha;
+  a.xcd_swizzle = swz_flags();
+  a.k_split = (a.K + 63) / 64 * 64;
+  if (rope_pos) {  // apply_rope in the epilogue, as in vtp_gemm_qkv_rope
+    a.xcd_swizzle |= 2;
+    a.rope_pos = rope_pos; a.rope_sin = (const bf16*)rope_sin; a.rope_cos = (const bf16*)rope_cos; a.rope_cols = rope_cols;
+  }
+  return launch_gemm8p_nt_fp8(a, epilogue, (hipStream_t)stream);
+}
+
 // qkv projection + apply_rope in one launch (attention.py:115 + :70-89): C bf16 [M, N] = A W^T + bias, then the q and k thirds
 // (columns < rope_cols) of every row m with rope_pos[m] >= 0 are rotated with row rope_pos[m] of the bf16 sin / cos tables.
 extern "C" int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* C, int ldc, int M, int N,

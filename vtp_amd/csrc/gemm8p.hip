@@ -56,9 +56,26 @@ __device__ __forceinline__ void p8_glds16(const char* sbase, unsigned voff, unsi
                : "memory");
 }
 
+typedef __attribute__((ext_vector_type(4))) int p8_i32x4;
+typedef __attribute__((ext_vector_type(8))) int p8_i32x8;
+// the MFMA operands of one 32-row (or 32-column) block over a k-tile of 128 bytes per row: four 16-B fragments for the bf16
+// 32x32x16 MFMA, or two 32-B register tuples for the fp8 32x32x64 one (each filled by two 16-B LDS reads -- same addresses)
+template <bool F8>
+struct P8Frags {
+  bf16x8 f[4];
+};
+template <>
+struct P8Frags<true> {
+  p8_i32x8 g[2];
+};
+
 template <int EPI, bool TRANS, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   constexpr bool STAGGER = !(VAR & 1), SETPRIO = !(VAR & 2), DMA_IN_MMA = (VAR & 4) != 0;
+  // VAR bit 3: the operands are fp8 (e4m3, OCP) -- same bytes, same staging, same fragment reads (the launcher passes K and the
+  // leading dimensions in 2-byte units); only the MFMA changes: v_mfma_f32_32x32x64_f8f6f4 takes 32 B per lane, i.e. two of
+  // the 16-B fragments, and A and B use the same (fragment, byte) -> k-slot map, so the dot products pair up the right elements
+  constexpr bool FP8 = (VAR & 8) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -211,39 +228,56 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     bf16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(b0 + 4 * 256));
     return __builtin_shufflevector(lo, h4, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  auto load_b = [&](const char* slot, bf16x8 (&f)[4]) {  // this wave's 32 columns of a B half-tile, k = 0..63
+  using Frags = P8Frags<FP8>;
+  auto load_rows = [&](const char* rows, Frags& fr) {  // NT: 32 rows of 128 B at `rows`, swizzled 16-B chunks 2 ks + hi
+    if constexpr (FP8) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if constexpr (!TRANS) f[ks] = *(const bf16x8*)(slot + wc * 4096 + rowoff + (((2 * ks + hi) ^ sw) << 4));
-      else f[ks] = tr_frag(slot, wc * 32, ks);
+      for (int kk = 0; kk < 2; ++kk) {
+        const p8_i32x4 c0 = *(const p8_i32x4*)(rows + rowoff + (((4 * kk + hi) ^ sw) << 4));
+        const p8_i32x4 c1 = *(const p8_i32x4*)(rows + rowoff + (((4 * kk + 2 + hi) ^ sw) << 4));
+        fr.g[kk] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fr.f[ks] = *(const bf16x8*)(rows + rowoff + (((2 * ks + hi) ^ sw) << 4));
     }
   };
-  auto load_a = [&](const char* slot, bf16x8 (&f)[2][4]) {  // this wave's 64 rows of an A half-tile
+  auto load_b = [&](const char* slot, Frags& fr) {  // this wave's 32 columns of a B half-tile, k = 0..63
+    if constexpr (!TRANS) load_rows(slot + wc * 4096, fr);
+    else {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+      for (int ks = 0; ks < 4; ++ks) fr.f[ks] = tr_frag(slot, wc * 32, ks);
+    }
+  };
+  auto load_a = [&](const char* slot, Frags (&fr)[2]) {  // this wave's 64 rows of an A half-tile
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if constexpr (!TRANS) f[jj][ks] = *(const bf16x8*)(slot + wr * 8192 + jj * 4096 + rowoff + (((2 * ks + hi) ^ sw) << 4));
-        else f[jj][ks] = tr_frag(slot, wr * 64 + jj * 32, ks);
+    for (int jj = 0; jj < 2; ++jj) {
+      if constexpr (!TRANS) load_rows(slot + wr * 8192 + jj * 4096, fr[jj]);
+      else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fr[jj].f[ks] = tr_frag(slot, wr * 64 + jj * 32, ks);
       }
+    }
   };
 
   // TN: column sums of A (bias gradient) ride along -- the wc == 0 waves of the first tile column add up the A fragments they
   // load anyway (v_dot2_f32_bf16 against ones: 4 VALU per fragment, in the shadow of the MFMAs), one atomic per row per tile
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   bool do_csum = false;
-  auto add_csum = [&](const bf16x8 (&f)[2][4], int jbase) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+  auto add_csum = [&](const Frags (&fr)[2], int jbase) {
+    if constexpr (!FP8) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const bf16x2_t v = {f[jj][ks][2 * w], f[jj][ks][2 * w + 1]};
-          csum[jbase + jj] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, csum[jbase + jj], false);
-        }
+          for (int w = 0; w < 4; ++w) {
+            const bf16x2_t v = {fr[jj].f[ks][2 * w], fr[jj].f[ks][2 * w + 1]};
+            csum[jbase + jj] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, csum[jbase + jj], false);
+          }
+    }
   };
   f32x16 acc[2][4];
   auto zero_acc = [&]() {
@@ -257,13 +291,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   zero_acc();
   // one MFMA segment: a 64 x 32 quadrant x k = 64.  jt: with DMA_IN_MMA the two LDS-DMA pieces of the half-tile under the
   // staging cursor are issued behind the 2nd and the 6th MFMA (their issue cost hides under the matrix pipe)
-  auto mma2 = [&](f32x16& c0, f32x16& c1, const bf16x8 (&w)[4], const bf16x8 (&x0)[4], const bf16x8 (&x1)[4], auto jt) {
+  auto mma2 = [&](f32x16& c0, f32x16& c1, const Frags& w, const Frags& x0, const Frags& x1, auto jt) {
     const bool dma = DMA_IN_MMA && s_h < H;
     if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);
+    if constexpr (FP8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.g[kk], x0.g[kk], c0, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3; zero scale operands select the unscaled v_mfma_f32_32x32x64_f8f6f4
+        c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.g[kk], x1.g[kk], c1, 0, 0, 0, 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x0[ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x1[ks], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x0.f[ks], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x1.f[ks], c1, 0, 0, 0);
       if constexpr (DMA_IN_MMA) {
         if (ks == 0 || ks == 2) {
           __builtin_amdgcn_sched_barrier(0);
@@ -307,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     if (STAGGER && wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
-      bf16x8 b1[4], b2[4], a1[2][4], a2[2][4];
+      Frags b1, b2, a1[2], a2[2];
       // ---- phase 0: B-first + A-first -> quadrant (cols 0..31, rows 0..63)
       load_b(kb, b1);
       __builtin_amdgcn_sched_barrier(0);
@@ -424,6 +465,16 @@ int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
     case EPI_F32_ATOMIC: return launch8p<EPI_F32_ATOMIC, false>(a, splits, s);
     case EPI_F32_SLAB: return launch8p<EPI_F32_SLAB, false>(a, splits, s);
     default: set_error("gemm8p: unsupported epilogue %d", epi); return VTP_ERR_ARG;
+  }
+}
+
+// fp8 (e4m3) operands, NT, forward epilogues only; `a` carries K, lda, ldb in 2-byte units (see the kernel's FP8 note)
+int launch_gemm8p_nt_fp8(const GemmArgs& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case EPI_BF16: return launch8p<EPI_BF16, false, 8>(a, 1, s);
+    case EPI_F32: return launch8p<EPI_F32, false, 8>(a, 1, s);
+    case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false, 8>(a, 1, s);
+    default: set_error("gemm8p fp8: unsupported epilogue %d", epi); return VTP_ERR_ARG;
   }
 }
 

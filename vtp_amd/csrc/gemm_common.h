@@ -149,8 +149,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             const f32x4 b2 = ok ? *(const f32x4*)(p.bias + n1 + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              x1[e] = acc[i][j][4 * q + e] + b1[e];
-              x2[e] = acc[i][j][4 * q + 4 + e] + b2[e];
+              x1[e] = acc[i][j][4 * q + e] * p.alpha + b1[e];
+              x2[e] = acc[i][j][4 * q + 4 + e] * p.alpha + b2[e];
             }
             const bf16x4 x1b = __builtin_convertvector(x1, bf16x4), x2b = __builtin_convertvector(x2, bf16x4);
 #pragma unroll
@@ -266,8 +266,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           f32x4 x1, x2, hsw;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            x1[e] = acc[i][j][4 * q + e] + b1[e];
-            x2[e] = acc[i][j][4 * q + 4 + e] + b2[e];
+            x1[e] = acc[i][j][4 * q + e] * p.alpha + b1[e];
+            x2[e] = acc[i][j][4 * q + 4 + e] * p.alpha + b2[e];
           }
           bf16x4 x1b = __builtin_convertvector(x1, bf16x4), x2b = __builtin_convertvector(x2, bf16x4);
           if (p.C2) {

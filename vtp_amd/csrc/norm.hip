@@ -12,7 +12,9 @@ constexpr int NORM_MAXC = 8;  // float4 chunks per lane -> D <= 8*64*4 = 2048 (t
 template <int KIND, int NC>  // KIND 0 rms, 1 layernorm; NC float4 chunks per lane
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, bf16* __restrict__ y,
-                                                       float* __restrict__ stats, int M, int D, float eps) {
+                                                       float* __restrict__ stats, int M, int D, float eps,
+                                                       uint8_t* __restrict__ y8 = nullptr, const float* __restrict__ q_scale = nullptr) {
+  // y8 / q_scale: the fp8 forward path -- the bf16-rounded output leaves as e4m3(y * q_scale[0]) (1 byte per element) instead
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -64,7 +66,18 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * wv[e] + bv[e];
       }
-      *(bf16x4*)(yr + col) = __builtin_convertvector(o, bf16x4);
+      const bf16x4 ob = __builtin_convertvector(o, bf16x4);
+      if (y8) {
+        const float qs = *q_scale;
+        float q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = fminf(fmaxf(bf2f(ob[e]) * qs, -448.f), 448.f);
+        uint32_t wq = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0u, false);
+        wq = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], wq, true);
+        *(uint32_t*)(y8 + (size_t)row * D + col) = wq;
+      } else {
+        *(bf16x4*)(yr + col) = ob;
+      }
     }
   }
   if (lane == 0 && stats) {
@@ -210,6 +223,19 @@ extern "C" int vtp_norm_fwd(const float* x, const float* w, const float* b, void
   else
     NORM_DISPATCH(norm_fwd_kernel, 1, x, w, b, (bf16*)y, stats, M, D, eps);
   return check_launch("norm_fwd");
+}
+
+extern "C" int vtp_norm_fwd_e4m3(const float* x, const float* w, const float* b, void* y8, const float* q_scale, float* stats, int M,
+                                 int D, float eps, int kind, void* stream) {
+  VTP_REQUIRE(x && w && y8 && q_scale, "vtp_norm_fwd_e4m3: null pointer");
+  VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_fwd_e4m3: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  VTP_REQUIRE(kind == 0 || (kind == 1 && b), "vtp_norm_fwd_e4m3: kind must be 0 (rms) or 1 (layernorm, needs bias)");
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (kind == 0)
+    NORM_DISPATCH(norm_fwd_kernel, 0, x, w, b, (bf16*)nullptr, stats, M, D, eps, (uint8_t*)y8, q_scale);
+  else
+    NORM_DISPATCH(norm_fwd_kernel, 1, x, w, b, (bf16*)nullptr, stats, M, D, eps, (uint8_t*)y8, q_scale);
+  return check_launch("norm_fwd_e4m3");
 }
 
 extern "C" int vtp_norm_bwd(const void* dy, const float* x, const float* w, const float* stats, const float* dres,

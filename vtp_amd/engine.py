@@ -653,6 +653,10 @@ class Stack:
         M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
+        fp8 = getattr(self, "fp8", None)
+        if fp8 is not None and fp8["ready"] and not train:
+            return self.forward_fp8(ws, x, segs, prefix_tokens, M)
+        calib = fp8["amax"] if (fp8 is not None and not fp8["ready"] and not train) else None
         saved_all = []
         rope_plan = self._rope_plan(ws, segs, prefix_tokens, M) if FUSE_ROPE else None
         for i, b in enumerate(self.blocks):
@@ -688,10 +692,74 @@ class Stack:
             else:
                 ops.gemm_nt(xn2, b.fc.w, hid, M=M, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias, epi=EPI_GELU)
             ops.gemm_nt(hid, b.w3.w, xout, M=M, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, resid=xmid, epi=EPI_F32)
+            if calib is not None:  # fp8 calibration pass: amax of the four GEMM inputs of this block
+                for j, tns in enumerate((xn1, o, xn2, hid)):
+                    ops.amax(tns, calib[i, j:j + 1])
             if train:
                 saved_all.append((x_in, xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid))
             x = xout
         self.last_saved = saved_all  # per-call context: several forward passes may be in flight before their backward
+        return x
+
+    # ---- fp8 (e4m3) inference forward: BASELINE config 5 (per-tensor scales: weights from their own amax, activations from a
+    # calibration pass of the bf16 path over representative images)
+    def fp8_begin_calibration(self):
+        if self.style != "vit" or self.D % 16 or self.H % 16 or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
+            raise NotImplementedError("fp8 forward: ViT blocks with D, H multiples of 16 and no LayerScale")
+        dev = self.store.device
+        self.fp8 = {"ready": False, "amax": torch.zeros(self.depth, 4, dtype=F32, device=dev)}
+
+    def fp8_finalize(self):
+        """weights -> e4m3 with scale 448 / amax(W); activation scales 448 / calibrated amax (x 1 / margin)"""
+        f, dev = self.fp8, self.store.device
+        amax = f["amax"].clamp_min(1e-12)
+        f["act_scale"] = (ops.E4M3_MAX / amax).contiguous()        # device [depth, 4]: read by the quantise kernels
+        act_inv = (amax / ops.E4M3_MAX).cpu().tolist()               # host: the GEMM alphas
+        f["w"], f["alpha"] = [], []
+        for i, b in enumerate(self.blocks):
+            ws8, al = [], []
+            for j, w in enumerate((b.qkv.w, b.proj.w, b.w12.w12, b.w3.w)):
+                wa = float(w.float().abs().max().clamp_min(1e-12))
+                q = torch.empty(w.shape, dtype=torch.uint8, device=dev)
+                ops.quantize_e4m3(w.contiguous(), q, ops.E4M3_MAX / wa)
+                ws8.append(q)
+                al.append(act_inv[i][j] * wa / ops.E4M3_MAX)
+            f["w"].append(ws8)
+            f["alpha"].append(al)
+        f["ready"] = True
+
+    def forward_fp8(self, ws: Workspace, x, segs, prefix_tokens: int, M: int):
+        """Stack.forward(train=False) with the four linear maps of every block on the fp8 MFMA path: norm / attention / SwiGLU
+        outputs are quantised (one extra row pass each) and multiplied against e4m3 weights; accumulation, bias, residual and
+        the attention itself are unchanged (fp32 / bf16)."""
+        D, H, heads, f = self.D, self.H, self.heads, self.fp8
+        scale = 1.0 / math.sqrt(64.0)
+        a8 = ws.get("f8.a", (M, max(D, H)), torch.uint8)
+        qkv = ws.get("qkv", (M, 3 * D), BF)
+        o = ws.get("o", (M, D), BF)
+        lse = ws.get("lse", (M * heads,), F32)
+        xmid = ws.get("xmid", (M, D), F32)
+        hid = ws.get("hid", (M, H), BF)
+        rope_plan = self._rope_plan(ws, segs, prefix_tokens, M) if FUSE_ROPE else None
+        rope_arg = None if rope_plan is None else (rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+        for i, b in enumerate(self.blocks):
+            w8, al, sc = f["w"][i], f["alpha"][i], f["act_scale"][i]
+            xout = ws.get(f"xout{i & 1}", (M, D), F32)
+            ops.norm_fwd_e4m3(x, b.n1w, b.n1b, a8, sc[0:1], None, M, D, self.eps, self.kind)  # norm + quantise in one pass
+            ops.gemm_nt_fp8(a8, w8[0], qkv, M=M, N=3 * D, K=D, alpha=al[0], bias=b.qkv.bias, epi=EPI_BF16, rope=rope_arg)
+            for r0, Bs, Ns, rp in self._attn_rows(segs):
+                q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
+                if rp is not None and rope_arg is None:
+                    ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
+                ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o_s, lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D,
+                             scale, self.causal)
+            ops.quantize_e4m3(o, a8, sc[1:2])
+            ops.gemm_nt_fp8(a8, w8[1], xmid, M=M, N=D, K=D, alpha=al[1], bias=b.proj.bias, resid=x, epi=EPI_F32)
+            ops.norm_fwd_e4m3(xmid, b.n2w, b.n2b, a8, sc[2:3], None, M, D, self.eps, self.kind)
+            ops.gemm_nt_fp8(a8, w8[2], hid, M=M, N=2 * H, K=D, alpha=al[2], bias=b.w12.b12, epi=EPI_SWIGLU)
+            ops.quantize_e4m3(hid, a8, sc[3:4])
+            ops.gemm_nt_fp8(a8, w8[3], xout, M=M, N=D, K=H, alpha=al[3], bias=b.w3.bias, resid=xmid, epi=EPI_F32)
+            x = xout
         return x
 
     def w3_colsum_target(self, i: int):

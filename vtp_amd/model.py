@@ -246,7 +246,37 @@ class VTPModel(nn.Module):
         st = self._engine()
         if self._param_version() != self._pver:
             self.refresh_weights()
+            if getattr(self, "_fp8_on", False):  # the e4m3 weight copies are derived data too
+                for stack in self._fp8_stacks():
+                    stack.fp8_finalize()
         return st
+
+    # ---- fp8 (e4m3) inference forward of the trunk and the pixel decoder (BASELINE config 5)
+    def _fp8_stacks(self):
+        self._engine()
+        return [self._trunk.stack] + ([self._decoder.stack] if self._decoder is not None else [])
+
+    @torch.no_grad()
+    def enable_fp8_forward(self, calibration_images: torch.Tensor):
+        """Switch the inference path (eval / no_grad: get_reconstruction_latents, get_latents_decoded_images, features) to fp8
+        MFMA GEMMs: one bf16 encode -> decode pass over `calibration_images` records the per-tensor activation maxima, the
+        weights are quantised from their own maxima.  Training and the autograd path are untouched (bf16)."""
+        self._fp8_on = False
+        for stack in self._fp8_stacks():
+            stack.fp8_begin_calibration()
+        lat = self._latents_nograd(calibration_images)
+        if self.pixel_decoder is not None:
+            self._decode_nograd(lat)
+        for stack in self._fp8_stacks():
+            stack.fp8_finalize()
+        self._fp8_on = True
+        return self
+
+    def disable_fp8_forward(self):
+        self._fp8_on = False
+        for stack in self._fp8_stacks():
+            stack.fp8 = None
+        return self
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients live in ONE flat buffer that every `p.grad` views (the fused optimizer / RCCL buckets use it directly):

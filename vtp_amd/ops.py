@@ -335,3 +335,38 @@ def latent_channel_stats(latents, sums):
     B, C = latents.shape[:2]
     hw = latents[0, 0].numel()
     _lib.check(_lib_().vtp_latent_channel_stats(_p(latents), _p(sums), B, C, hw, _s()), "vtp_latent_channel_stats")
+
+
+# ---- fp8 (e4m3) forward path: BASELINE config 5
+E4M3_MAX = 448.0
+
+
+def quantize_e4m3(src, dst, scale):
+    """dst uint8 [n] = e4m3(clamp(src * scale)); src bf16 or f32; scale: float or a device f32 tensor"""
+    n = src.numel()
+    sd, sf = (scale, 0.0) if isinstance(scale, torch.Tensor) else (None, float(scale))
+    _lib.check(_lib_().vtp_quantize_e4m3(_p(src), int(src.dtype == torch.float32), _p(dst), n, _p(sd), sf, _s()), "vtp_quantize_e4m3")
+
+
+def norm_fwd_e4m3(x, w, b, y8, q_scale, stats, M, D, eps, kind):
+    _lib.check(_lib_().vtp_norm_fwd_e4m3(_p(x), _p(w), _p(b), _p(y8), _p(q_scale), _p(stats), M, D, eps, kind, _s()), "vtp_norm_fwd_e4m3")
+
+
+def amax(src, out):
+    _lib.check(_lib_().vtp_amax(_p(src), int(src.dtype == torch.float32), src.numel(), _p(out), _s()), "vtp_amax")
+
+
+def dequantize_e4m3(src, dst, inv_scale):
+    _lib.check(_lib_().vtp_dequantize_e4m3(_p(src), _p(dst), src.numel(), float(inv_scale), _s()), "vtp_dequantize_e4m3")
+
+
+def gemm_nt_fp8(a8, b8, c, *, M, N, K, alpha, lda=None, ldb=None, ldc=None, c2=None, ldc2=0, bias=None, resid=None, epi=EPI_BF16,
+                rope=None):
+    """c[M,N] = alpha * a8[M,K] @ b8[N,K]^T (+ bias, + resid | SwiGLU); a8 / b8 uint8 tensors holding e4m3;
+    rope = (rope_pos, rope_sin, rope_cos, rope_cols): apply_rope fused into the bf16 epilogue"""
+    lda = K if lda is None else lda
+    ldb = K if ldb is None else ldb
+    ldc = c.stride(0) if ldc is None else ldc
+    rp = (None, None, None, 0) if rope is None else rope
+    _lib.check(_lib_().vtp_gemm_nt_fp8(_p(a8), lda, _p(b8), ldb, _p(c), ldc, _p(c2), ldc2, _p(bias), _p(resid), M, N, K, epi, float(alpha),
+                                       _p(rp[0]), _p(rp[1]), _p(rp[2]), rp[3], _s()), "vtp_gemm_nt_fp8")
