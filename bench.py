@@ -534,8 +534,8 @@ def main():
                     "mean_lpips": round(float(tr2.lpips_val.mean()), 5), "weights": "seeded random VGG16 (vgg.pth is a download)"}
         model = m2
     out = {
-        "metric": "images/sec/node VTP-B f16d64 256x256 train step" if args.workload.startswith("vtp_base")
-        else "images/sec/node VTP-S f16d64 256x256 train step",
+        "metric": {"vtp_base": "images/sec/node VTP-B f16d64 256x256 train step", "vtp_smal": "images/sec/node VTP-S f16d64 256x256 train step",
+                   "vtp_larg": "images/sec/node VTP-L f16d64 512x512 train step"}[args.workload[:8]],
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
