@@ -310,9 +310,32 @@ class VTPModel(nn.Module):
     # ------------------------------------------------------------------------------------------------ API (inference)
     @staticmethod
     def _img(image: torch.Tensor) -> torch.Tensor:
-        if image.ndim != 4 or image.shape[1] != 3 or image.shape[2] % 16 or image.shape[3] % 16:
-            raise ValueError(f"image must be [B,3,H,W] with H,W multiples of 16, got {tuple(image.shape)}")
+        """API-boundary check: the kernels take raw device pointers, so shape, device, dtype and layout are settled here (any float
+        dtype / memory format is converted; a host tensor is an error, never a silent copy or a fault)"""
+        if not isinstance(image, torch.Tensor) or image.ndim != 4 or image.shape[1] != 3 or image.shape[2] % 16 or image.shape[3] % 16:
+            raise ValueError(f"image must be a [B,3,H,W] tensor with H,W multiples of 16, got {tuple(getattr(image, 'shape', ()))}")
+        if not image.is_cuda:
+            raise ValueError("image must live on the MI355X (got a CPU tensor): move it with .cuda() -- there is no CPU path")
+        if not image.is_floating_point():
+            raise ValueError(f"image must be a floating-point tensor, got {image.dtype}")
         return image.detach().to(dtype=torch.float32).contiguous()
+
+    def _ids(self, text: torch.Tensor, check_range: bool = True) -> torch.Tensor:
+        """token ids -> int64 [B, context_length], contiguous, on the device; out-of-range ids raise (the embedding kernel indexes
+        the table with them).  check_range costs one host sync: the inference API pays it, the trainer's hot path does not."""
+        T = self.config.text_context_length
+        if not isinstance(text, torch.Tensor) or text.ndim != 2 or text.shape[1] != T:
+            raise ValueError(f"text must be [B, {T}] token ids, got {tuple(getattr(text, 'shape', ()))}")
+        if not text.is_cuda:
+            raise ValueError("text must live on the MI355X (got a CPU tensor)")
+        if text.is_floating_point() or text.dtype == torch.bool:
+            raise ValueError(f"text must hold integer token ids, got {text.dtype}")
+        ids = text.detach().to(dtype=torch.int64).contiguous()
+        if check_range and ids.numel():
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.config.text_vocab_size:
+                raise ValueError(f"token ids must be in [0, {self.config.text_vocab_size}), got [{lo}, {hi}]")
+        return ids
 
     def get_reconstruction_latents(self, image: torch.Tensor) -> torch.Tensor:
         """modeling_vtp.py:337-360 -> [B, 64, H/16, W/16] (f32).  Differentiable (autograd.EncodeLatents) when autograd is
@@ -379,9 +402,12 @@ class VTPModel(nn.Module):
         h, w = H // 16, W // 16
         tr = self._trunk
         depth = tr.depth
-        take = list(range(depth - n, depth)) if isinstance(n, int) else [int(i) for i in n]
-        if not take or any(i < 0 or i >= depth for i in take):
-            raise AssertionError(f"only {len([i for i in take if 0 <= i < depth])} / {len(take)} blocks found")
+        # the reference walks the blocks in order and collects those listed (vision_transformer.py:266-281): ascending block order
+        # whatever the order of `n`, and its length assert fails on duplicates or indices outside the trunk
+        want = list(range(depth - n, depth)) if isinstance(n, int) else [int(i) for i in n]
+        take = sorted(set(i for i in want if 0 <= i < depth))
+        if not take or len(take) != len(want):
+            raise AssertionError(f"only {len(take)} / {len(want)} blocks found")
         tr.forward(img, train=True, tag="intermediate")  # train=True keeps every block's output buffer
         c = tr.ctx()
         M, D = c.M, tr.D
@@ -447,10 +473,8 @@ class VTPModel(nn.Module):
         """modeling_vtp.py:278-310.  Differentiable in training mode (autograd.TextFeature)."""
         if not self.config.train_clip:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
-        if text.ndim != 2 or text.shape[1] != self.config.text_context_length:
-            raise ValueError(f"text must be [B, {self.config.text_context_length}] token ids, got {tuple(text.shape)}")
         if ag.grad_mode(self):
-            ids = text.detach().to(dtype=torch.int64).contiguous()
+            ids = self._ids(text)
             f = ag.TextFeature.apply(ids, ag.anchor(self), self)
             return torch.nn.functional.normalize(f, dim=-1) if normalize else f
         return self._clip_text_nograd(text, normalize)
@@ -458,7 +482,7 @@ class VTPModel(nn.Module):
     @torch.no_grad()
     def _clip_text_nograd(self, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         self._fresh()
-        ids = text.detach().to(dtype=torch.int64).contiguous()
+        ids = self._ids(text)
         f = self._text.forward(ids, train=False)
         if normalize:
             f, _ = self._clip.normalize(f, "txt")

@@ -729,6 +729,9 @@ class VTPTrainer:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
         if text is not None and self._clip_unsupported:
             raise NotImplementedError(self._clip_unsupported)
+        images = self.model._img(images)  # shape / device / dtype / layout settled at the boundary (raw pointers below)
+        if text is not None:
+            text = self.model._ids(text, check_range=False)
         B, _, H, W = images.shape
         self._set_hyper()
         self._draw_drop_plans(B, ssl)
