@@ -142,3 +142,49 @@ def test_center_crop_arr_matches_reference():
         im = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
         a, b = np.asarray(center_crop_arr(im, size)), np.asarray(ref.center_crop_arr(im, size))
         assert a.shape == (size, size, 3) and np.array_equal(a, b)
+
+
+def test_from_vtp_yaml_matches_reference(tmp_path):
+    """VTPConfig.from_vtp_yaml against the reference classmethod (configuration_vtp.py:169-234) on a synthetic legacy YAML; the
+    reference reads it with OmegaConf, which is stubbed here by a tiny attribute-dict loader over PyYAML"""
+    import sys
+
+    import yaml
+    from vtp_amd import VTPConfig
+    doc = {"data": {"image_size": 224},
+           "training": {"train_clip": True, "train_reconstruction": True, "init_logit_scale": 2.0, "nonscalar_logit_scale": False},
+           "vtp_model": {
+               "vision_encoder": {"patch_size": 16, "embed_dim": 384, "depth": 12, "num_heads": 6, "mlp_ratio": 4.0, "ffn_layer": "swiglu",
+                                  "norm_type": "rmsnorm", "vit_feature_bottleneck": 64, "bottleneck_ae_only": True, "clip_feat": "cls"},
+               "text_encoder": {"context_length": 77, "vocab_size": 49408, "embed_dim": 384, "heads": 6, "layers": 12, "mlp_ratio": 4.0,
+                                "embed_cls": False, "pad_id": 0, "no_causal_mask": False, "pool_type": "argmax", "proj_type": "linear",
+                                "proj_bias": False, "output_tokens": False, "quick_gelu": False},
+               "pixel_decoder": {"embed_dim": 384, "num_heads": 6, "depth": 12, "ffn_layer": "swiglu", "norm_layer": "layernorm"}}}
+    path = str(tmp_path / "legacy.yaml")
+    with open(path, "w") as fh:
+        yaml.safe_dump(doc, fh)
+    ours = VTPConfig.from_vtp_yaml(path)
+
+    class AttrDict(dict):
+        def __getattr__(self, k):
+            v = self[k]
+            return AttrDict(v) if isinstance(v, dict) else v
+
+    ns = load_reference()  # installs the omegaconf import stub of oracle/ref_stubs.py
+    om = sys.modules["omegaconf"]
+    had = getattr(om.OmegaConf, "load", None)
+    om.OmegaConf.load = staticmethod(lambda p: AttrDict(yaml.safe_load(open(p))))
+    try:
+        ref = ns.VTPConfig.from_vtp_yaml(path)
+    finally:
+        if had is not None:
+            om.OmegaConf.load = had
+    rd = ref.to_dict()
+    for k, v in ours.to_dict().items():
+        assert rd[k] == v, (k, rd[k], v)
+    bad = dict(doc)
+    bad["data"] = {}
+    with open(path, "w") as fh:
+        yaml.safe_dump(bad, fh)
+    with pytest.raises(KeyError):
+        VTPConfig.from_vtp_yaml(path)

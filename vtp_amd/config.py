@@ -104,6 +104,47 @@ class VTPConfig:
         with open(os.path.join(path, "config.json")) as fh:
             return cls.from_dict(json.load(fh))
 
+    # legacy training YAML -> HF config (configuration_vtp.py:169-234).  (yaml section, yaml key) -> constructor keyword; a missing
+    # optional key keeps the constructor default.  PyYAML instead of the reference's OmegaConf: plain nested mappings suffice.
+    _YAML_MAP = {
+        ("data", "image_size"): "image_size",
+        ("training", "train_clip"): "train_clip", ("training", "train_reconstruction"): "train_reconstruction",
+        ("training", "init_logit_scale"): "init_logit_scale", ("training", "init_logit_bias"): "init_logit_bias",
+        ("training", "nonscalar_logit_scale"): "nonscalar_logit_scale",
+        ("vision", "patch_size"): "vision_patch_size", ("vision", "embed_dim"): "vision_embed_dim", ("vision", "depth"): "vision_depth",
+        ("vision", "num_heads"): "vision_num_heads", ("vision", "mlp_ratio"): "vision_mlp_ratio", ("vision", "ffn_layer"): "vision_ffn_layer",
+        ("vision", "norm_type"): "vision_norm_layer", ("vision", "init_values"): "vision_init_values",
+        ("vision", "use_qk_norm"): "vision_use_qk_norm", ("vision", "vit_feature_bottleneck"): "vision_feature_bottleneck",
+        ("vision", "bottleneck_ae_only"): "vision_bottleneck_ae_only", ("vision", "clip_feat"): "vision_clip_feat",
+        ("text", "context_length"): "text_context_length", ("text", "vocab_size"): "text_vocab_size", ("text", "embed_dim"): "text_embed_dim",
+        ("text", "heads"): "text_num_heads", ("text", "layers"): "text_depth", ("text", "mlp_ratio"): "text_mlp_ratio",
+        ("text", "ls_init_value"): "text_ls_init_value", ("text", "embed_cls"): "text_embed_cls", ("text", "pad_id"): "text_pad_id",
+        ("text", "no_causal_mask"): "text_no_causal_mask", ("text", "pool_type"): "text_pool_type", ("text", "proj_type"): "text_proj_type",
+        ("text", "proj_bias"): "text_proj_bias", ("text", "output_tokens"): "text_output_tokens", ("text", "quick_gelu"): "text_quick_gelu",
+        ("decoder", "embed_dim"): "decoder_embed_dim", ("decoder", "num_heads"): "decoder_num_heads", ("decoder", "depth"): "decoder_depth",
+        ("decoder", "ffn_layer"): "decoder_ffn_layer", ("decoder", "norm_layer"): "decoder_norm_layer",
+        ("decoder", "layerscale_init"): "decoder_init_values", ("decoder", "use_qk_norm"): "decoder_use_qk_norm",
+    }
+    _YAML_OPTIONAL = {"vision_init_values", "vision_use_qk_norm", "text_ls_init_value", "decoder_init_values", "decoder_use_qk_norm",
+                      "init_logit_scale", "init_logit_bias", "nonscalar_logit_scale"}
+
+    @classmethod
+    def from_vtp_yaml(cls, yaml_path: str) -> "VTPConfig":
+        """VTPConfig from a legacy VTP training YAML (sections data / training / vtp_model.{vision_encoder, text_encoder,
+        pixel_decoder}) -- same key mapping as the reference's classmethod; a required key that is absent raises KeyError."""
+        import yaml
+        with open(yaml_path) as fh:
+            cfg = yaml.safe_load(fh)
+        sections = {"data": cfg["data"], "training": cfg["training"], "vision": cfg["vtp_model"]["vision_encoder"],
+                    "text": cfg["vtp_model"]["text_encoder"], "decoder": cfg["vtp_model"]["pixel_decoder"]}
+        kw = {}
+        for (sec, key), arg in cls._YAML_MAP.items():
+            if key in sections[sec]:
+                kw[arg] = sections[sec][key]
+            elif arg not in cls._YAML_OPTIONAL:
+                raise KeyError(f"{yaml_path}: missing {sec}.{key}")
+        return cls(**kw)
+
 
 def swiglu_hidden(dim: int, ratio: float = 4.0, align_to: int = 8) -> int:
     """SwiGLUFFN hidden width -- ffn.py:71-72 (with mlp_hidden_dim = int(dim*ffn_ratio), block.py:176)."""
