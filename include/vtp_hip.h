@@ -90,6 +90,12 @@ int vtp_scatter_image_rows(const float* src, const int* img_idx, float* dst, int
 int vtp_layerscale_wgrad(const float* G, const float* W, const float* bias, const float* colsum, const float* gamma, float* dW,
                          float* db, float* dgamma, int N, int K, void* stream);
 int vtp_scaled_transpose(const float* W, const float* gamma, void* dstT, int N, int K, void* stream);
+/* QK normalisation (attention.py:67-68,119-120): q = RMSNorm(64)(q), k likewise (weights wq / wk [64], shared by the heads), before
+ * RoPE.  qkv bf16 [M, 3D] -> out (v copied), inv f32 [M, 2 D / 64] = rsqrt(mean x^2 + eps) per (row, part, head);
+ * backward in place on the q / k parts of dqkv, dwq / dwk accumulated. */
+int vtp_qk_norm_fwd(const void* qkv, const float* wq, const float* wk, void* out, float* inv, long M, int D, float eps, void* stream);
+int vtp_qk_norm_bwd(void* dqkv, const void* qkv, const float* inv, const float* wq, const float* wk, float* dwq, float* dwk, long M, int D,
+                    void* stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------
  * kind 0 = RMSNorm (normalization.py:17-22, eps 1e-5, no bias), 1 = LayerNorm (vision_transformer.py:30-34

@@ -104,8 +104,13 @@ def self_attention(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int,
     qkv = qkv.reshape(B, N, 3, num_heads, C // num_heads)
     q, k, v = torch.unbind(qkv, 2)
     q, k, v = [t.transpose(1, 2) for t in (q, k, v)]
+    if pre + "q_norm.weight" in sd:  # use_qk_norm: RMSNorm(head_dim) on q and k (attention.py:67-68,119-120)
+        q = rmsnorm(q, sd[pre + "q_norm.weight"])
+        k = rmsnorm(k, sd[pre + "k_norm.weight"])
     if rope is not None:
         q, k = apply_rope(q, k, rope[0], rope[1])
+    if q.dtype != v.dtype:  # under autocast the fp32 norm weight promotes q, k; SDPA is an autocast op and casts them back
+        q, k = q.to(v.dtype), k.to(v.dtype)
     o = F.scaled_dot_product_attention(q, k, v)  # scale 1/sqrt(d), no mask  (attention.py:124)
     o = o.transpose(1, 2).reshape(B, N, C)
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])

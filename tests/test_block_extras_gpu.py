@@ -155,3 +155,60 @@ def test_stochastic_depth_step_vs_oracle(init_values):
     print("drop eager:", res[0], "graphs:", res[1])
     for a, b in zip(*res):
         assert abs(a - b) < 2e-3 * abs(a)
+
+
+def test_qk_norm_forward_and_gradients_vs_oracle():
+    """use_qk_norm in trunk and decoder: encode / decode outputs and the rec-step gradients (incl. the q / k norm weights) against
+    the oracle's autograd; eager == hipGraph segments"""
+    from oracle import vtp_oracle as O
+    from oracle.ref_stubs import TINY
+    from vtp_amd import VTPConfig, VTPModel, VTPTrainer
+    torch.manual_seed(11)
+    cfg = VTPConfig(**dict(TINY, vision_use_qk_norm=True, decoder_use_qk_norm=True))
+    m = VTPModel(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "q_norm" in n or "k_norm" in n:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    img = torch.randn(2, 3, cfg.image_size, cfg.image_size)
+
+    def oracle(autocast):
+        sd = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd0.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            lat = O.reconstruction_latents(sd, img, 2)
+            rec = O.decoder_forward(sd, lat.float(), 2)
+            loss = O.l1_loss(rec, img)
+        loss.backward()
+        return sd, lat.detach().float(), rec.detach().float(), float(loss)
+
+    ref, lat_r, rec_r, loss_r = oracle(False)
+    noisy, lat_n, rec_n, _ = oracle(True)
+    m.eval()
+    with torch.no_grad():
+        lat = m.get_reconstruction_latents(img.to(DEV))
+        rec = m.get_latents_decoded_images(lat)
+    e1, e1r = relF(lat, lat_r), relF(lat_n, lat_r)
+    e2, e2r = relF(rec, rec_r), relF(rec_n, rec_r)
+    print(f"qk-norm latents E_ours={e1:.3e} E_ref={e1r:.3e}; recon E_ours={e2:.3e} E_ref={e2r:.3e}")
+    assert e1 <= max(1.5 * e1r, 1e-2) and e2 <= max(1.5 * e2r, 2e-2)
+    m.train()
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0)
+    loss = float(tr.step(img.to(DEV))[0])
+    assert abs(loss - loss_r) < 3e-3 * loss_r
+    params = dict(m.named_parameters())
+    for k in ("trunk.blocks.0.attn.q_norm.weight", "trunk.blocks.1.attn.k_norm.weight", "pixel_decoder.blocks.0.attn.k_norm.weight",
+              "trunk.blocks.0.attn.qkv.weight", "trunk.patch_embed.proj.weight", "pixel_decoder.blocks.0.attn.qkv.weight"):
+        e, er = relF(params[k].grad, ref[k].grad), relF(noisy[k].grad, ref[k].grad)
+        print(f"  grad {k}: E_ours={e:.3e} E_ref={er:.3e}")
+        assert e <= max(1.5 * er, 3e-2), k
+    res = []
+    for use_graphs in (False, True):
+        m2 = VTPModel(cfg)
+        m2.load_state_dict(sd0)
+        t2 = VTPTrainer(m2.to(DEV), lr=1e-3, weight_decay=0.0, use_graphs=use_graphs)
+        res.append([float(t2.step(img.to(DEV))[0]) for _ in range(4)])
+    assert res[0][-1] < res[0][0]
+    for a, b in zip(*res):
+        assert abs(a - b) < 1e-3 * abs(a)

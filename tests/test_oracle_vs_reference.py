@@ -188,3 +188,31 @@ def test_from_vtp_yaml_matches_reference(tmp_path):
         yaml.safe_dump(bad, fh)
     with pytest.raises(KeyError):
         VTPConfig.from_vtp_yaml(path)
+
+
+def test_qk_norm_branch_matches_reference():
+    """use_qk_norm (attention.py:67-68,119-120) in trunk and pixel decoder: oracle == reference, outputs and gradients"""
+    ns = load_reference()
+    torch.manual_seed(5)
+    cfg = dict(TINY)
+    cfg.update(image_size=64, vision_use_qk_norm=True, decoder_use_qk_norm=True)
+    m = ns.VTPModel(ns.VTPConfig(**cfg)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "q_norm" in n or "k_norm" in n:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+    sd = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in m.state_dict().items()}
+    assert any("q_norm.weight" in k for k in sd)
+    img = torch.randn(2, 3, 64, 64)
+    lat_ref = m.get_reconstruction_latents(img)
+    rec_ref = m.get_latents_decoded_images(lat_ref)
+    lat = O.reconstruction_latents(sd, img, 2)
+    rec = O.decoder_forward(sd, lat, 2)
+    torch.testing.assert_close(lat, lat_ref, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(rec, rec_ref, rtol=2e-4, atol=2e-5)
+    (rec_ref - img).abs().mean().backward()
+    (rec - img).abs().mean().backward()
+    params = dict(m.named_parameters())
+    for k in ("trunk.blocks.0.attn.q_norm.weight", "trunk.blocks.1.attn.k_norm.weight", "pixel_decoder.blocks.0.attn.q_norm.weight",
+              "trunk.blocks.0.attn.qkv.weight"):
+        torch.testing.assert_close(sd[k].grad, params[k].grad, rtol=2e-3, atol=1e-6)

@@ -44,6 +44,8 @@ SIGNATURES = {
     "vtp_scatter_image_rows": [_P, _P, _P, _I, _L, _I, _F, _I, _P],
     "vtp_layerscale_wgrad": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vtp_scaled_transpose": [_P, _P, _P, _I, _I, _P],
+    "vtp_qk_norm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "vtp_qk_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
     "vtp_norm_fwd_e4m3": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "vtp_quantize_e4m3": [_P, _I, _P, _L, _P, _F, _P],

@@ -75,7 +75,6 @@ class VTPConfig:
         need(self.vision_ffn_layer == "swiglu" and self.decoder_ffn_layer == "swiglu", "only the swiglu FFN is implemented")
         need(self.vision_norm_layer in ("rmsnorm", "layernorm"), "vision_norm_layer must be rmsnorm|layernorm")
         need(self.decoder_norm_layer in ("rmsnorm", "layernorm"), "decoder_norm_layer must be rmsnorm|layernorm")
-        need(not self.vision_use_qk_norm and not self.decoder_use_qk_norm, "qk-norm is not implemented")
         need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
         need(not self.text_embed_cls and self.text_pool_type == "argmax" and not self.text_no_causal_mask,
              "text tower: only the causal / argmax-pooled CLIP configuration is implemented")

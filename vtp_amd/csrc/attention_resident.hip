@@ -577,6 +577,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   __syncthreads();
   if (q0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
+  const f32x2 sc2v = {sc2, sc2}, nlse = {-lse2, -lse2}, scv = {p.scale, p.scale}, ndlt = {-dlt * p.scale, -dlt * p.scale};
   const int nkb = p.npad >> 5, last = nkb - 1;
   f32x16 dq[2];
   zero16r(dq[0]);
@@ -590,9 +591,20 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Ks, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vs, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
     }
+    // dS = P (.) (dP - delta) * scale with P = exp2(S sc2 - lse2): packed fp32 (two scores per v_pk_fma / v_pk_mul) around the
+    // two quarter-rate exponentials -- the VALU work, not the 12 MFMAs, is what bounds this loop
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * sc2 - lse2) * (dp[r] - dlt) * p.scale;
-    if (kb == last) {
+    for (int i = 0; i < 8; ++i) {
+      f32x2 e = {s[2 * i], s[2 * i + 1]}, g = {dp[2 * i], dp[2 * i + 1]};
+      e = __builtin_elementwise_fma(e, sc2v, nlse);
+      g = __builtin_elementwise_fma(g, scv, ndlt);
+      e[0] = fast_exp2(e[0]);
+      e[1] = fast_exp2(e[1]);
+      e *= g;
+      s[2 * i] = e[0];
+      s[2 * i + 1] = e[1];
+    }
+    if (kb == last && (p.N & 31)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.N) s[r] = 0.f;
@@ -634,8 +646,8 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   const long srow0 = ((long)b * p.heads + h) * p.N;
   for (int i = threadIdx.x; i < p.npad; i += blockDim.x) {
     const int qn = min(i, p.N - 1);
-    lse_s[i] = p.lse[srow0 + qn] * LOG2E_R;
-    dlt_s[i] = p.delta[srow0 + qn];
+    lse_s[i] = -p.lse[srow0 + qn] * LOG2E_R;  // pre-negated / pre-scaled: they enter the key loop as fma addends
+    dlt_s[i] = -p.delta[srow0 + qn] * p.scale;
   }
   const int k0 = (blockIdx.z * nwaves + wave) * 32, ki = k0 + (lane & 31), kc = min(ki, p.N - 1);
   bf16x8 kf[4], vf[4];
@@ -652,6 +664,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   __syncthreads();
   if (k0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
+  const f32x2 sc2v = {sc2, sc2}, scv = {p.scale, p.scale};
   const int nqb = p.npad >> 5, last = nqb - 1;
   f32x16 dk[2], dv[2];
   zero16r(dk[0]);
@@ -670,15 +683,25 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
     f32x16 pr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *(const f32x4*)(lse_s + qblk * 32 + 8 * g + 4 * hi);
-      const f32x4 d4 = *(const f32x4*)(dlt_s + qblk * 32 + 8 * g + 4 * hi);
+      const f32x4 l4 = *(const f32x4*)(lse_s + qblk * 32 + 8 * g + 4 * hi);  // -lse * log2(e) of the four query rows
+      const f32x4 d4 = *(const f32x4*)(dlt_s + qblk * 32 + 8 * g + 4 * hi);  // -delta * scale
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        float pv = fast_exp2(s[r] * sc2 - l4[e]);
-        if (qblk == last && qblk * 32 + 8 * g + 4 * hi + e >= p.N) pv = 0.f;
-        pr[r] = pv;
-        s[r] = pv * (dp[r] - d4[e]) * p.scale;
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int r = 4 * g + 2 * e2;
+        f32x2 e = {s[r], s[r + 1]}, gq = {dp[r], dp[r + 1]};
+        e = __builtin_elementwise_fma(e, sc2v, f32x2{l4[2 * e2], l4[2 * e2 + 1]});
+        gq = __builtin_elementwise_fma(gq, scv, f32x2{d4[2 * e2], d4[2 * e2 + 1]});
+        e[0] = fast_exp2(e[0]);
+        e[1] = fast_exp2(e[1]);
+        if (qblk == last && (p.N & 31)) {
+          if (qblk * 32 + 8 * g + 4 * hi + 2 * e2 >= p.N) e[0] = 0.f;
+          if (qblk * 32 + 8 * g + 4 * hi + 2 * e2 + 1 >= p.N) e[1] = 0.f;
+        }
+        pr[r] = e[0];
+        pr[r + 1] = e[1];
+        e *= gq;
+        s[r] = e[0];
+        s[r + 1] = e[1];
       }
     }
     const bf16x8 p0 = pack8r(pr, 0), p1 = pack8r(pr, 8), d0 = pack8r(s, 0), d1 = pack8r(s, 8);

@@ -87,6 +87,91 @@ __global__ __launch_bounds__(256) void scaled_transpose_kernel(const float* __re
   }
 }
 
+// QK normalisation (attention.py:67-68,119-120: q = RMSNorm(head_dim)(q), k likewise, before RoPE; weights [64] shared by the
+// heads).  qkv bf16 [M, 3D] as the projection packs it; a (row, head) of q or k is 64 elements = eight 16-B chunks = eight
+// consecutive lanes.  out = bf16(bf16(x * rsqrt(mean x^2 + eps)) * w) for the q / k parts (the reference's `.type_as(x) * weight`
+// followed by the bf16 cast of apply_rope / SDPA), v is copied; inv [M, 2 heads] keeps rsqrt(..) for the backward.
+__global__ __launch_bounds__(256) void qk_norm_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ wq,
+                                                          const float* __restrict__ wk, bf16* __restrict__ out, float* __restrict__ inv,
+                                                          long M, int D, float eps) {
+  const int cpr = 3 * D / 8, cpp = D / 8;  // 16-B chunks per row / per part
+  const long total = M * cpr;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < (total + 255) / 256 * 256; i += (long)gridDim.x * 256L) {
+    const bool live = i < total;
+    const long row = live ? i / cpr : 0;
+    const int c = live ? (int)(i - row * cpr) : 0, part = c / cpp, d0 = (c % 8) * 8;
+    bf16x8 v = live ? *(const bf16x8*)(qkv + row * 3 * D + (long)c * 8) : bf16x8{};
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += bf2f(v[e]) * bf2f(v[e]);
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    if (!live) continue;
+    if (part < 2) {
+      const float r = rsqrtf(ss * (1.f / 64.f) + eps);
+      const float* w = part == 0 ? wq : wk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(f2bf(bf2f(v[e]) * r)) * w[d0 + e]);
+      if ((c & 7) == 0) inv[row * (2 * D / 64) + (c / 8)] = r;  // chunk / 8 = part * heads + head
+    }
+    *(bf16x8*)(out + row * 3 * D + (long)c * 8) = v;
+  }
+}
+
+// in place on the q / k parts of dqkv (gradient w.r.t. the normalised, un-rotated q, k): with xh = x * inv, g = dy (.) w,
+//   dx = inv * (g - xh * mean(g (.) xh)),   dw[d] += sum over rows and heads of dy[d] * bf16(xh[d])
+__global__ __launch_bounds__(256) void qk_norm_bwd_kernel(bf16* __restrict__ dqkv, const bf16* __restrict__ qkv, const float* __restrict__ inv,
+                                                          const float* __restrict__ wq, const float* __restrict__ wk, float* __restrict__ dwq,
+                                                          float* __restrict__ dwk, long M, int D) {
+  __shared__ float red[2][64];
+  const int cpr = 2 * D / 8, cpp = D / 8;  // only the q / k chunks
+  const long total = M * cpr;
+  if (threadIdx.x < 128) red[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
+  __syncthreads();
+  float dw[2][8] = {};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < (total + 255) / 256 * 256; i += (long)gridDim.x * 256L) {
+    const bool live = i < total;
+    const long row = live ? i / cpr : 0;
+    const int c = live ? (int)(i - row * cpr) : 0, part = c / cpp, d0 = (c % 8) * 8;
+    const long off = row * 3 * D + (long)c * 8;
+    const bf16x8 x = live ? *(const bf16x8*)(qkv + off) : bf16x8{};
+    const bf16x8 dy = live ? *(const bf16x8*)(dqkv + off) : bf16x8{};
+    const float r = live ? inv[row * (2 * D / 64) + (c / 8)] : 0.f;
+    const float* w = part == 0 ? wq : wk;
+    float xh[8], g[8], dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xh[e] = bf2f(x[e]) * r;
+      g[e] = bf2f(dy[e]) * w[d0 + e];
+      dot += g[e] * xh[e];
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (!live) continue;
+    dot *= 1.f / 64.f;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = f2bf(r * (g[e] - xh[e] * dot));
+      dw[part][e] += bf2f(dy[e]) * bf2f(f2bf(xh[e]));
+    }
+    *(bf16x8*)(dqkv + off) = o;
+  }
+  // a thread always sees the same d0 (256 and the chunk counts are multiples of 8): LDS reduce, then one atomic per d and block
+  const int d0 = (threadIdx.x % 8) * 8;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&red[pt][d0 + e], dw[pt][e]);
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const float v = red[threadIdx.x >> 6][threadIdx.x & 63];
+    if (v != 0.f) atomicAdd((threadIdx.x >> 6 ? dwk : dwq) + (threadIdx.x & 63), v);
+  }
+}
+
 }  // namespace vtp
 using namespace vtp;
 
@@ -124,4 +209,21 @@ extern "C" int vtp_scaled_transpose(const float* W, const float* gamma, void* ds
   hipLaunchKernelGGL(scaled_transpose_kernel, dim3(cdiv(K, 64), cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, W, gamma,
                      (bf16*)dstT, N, K);
   return check_launch("scaled_transpose");
+}
+
+extern "C" int vtp_qk_norm_fwd(const void* qkv, const float* wq, const float* wk, void* out, float* inv, long M, int D, float eps,
+                               void* stream) {
+  VTP_REQUIRE(qkv && wq && wk && out && inv && M > 0 && D > 0 && D % 64 == 0, "vtp_qk_norm_fwd: bad argument (head_dim 64: D %% 64 == 0)");
+  hipLaunchKernelGGL(qk_norm_fwd_kernel, dim3(extras_grid(M * (3 * D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, wq, wk,
+                     (bf16*)out, inv, M, D, eps);
+  return check_launch("qk_norm_fwd");
+}
+
+extern "C" int vtp_qk_norm_bwd(void* dqkv, const void* qkv, const float* inv, const float* wq, const float* wk, float* dwq, float* dwk,
+                               long M, int D, void* stream) {
+  VTP_REQUIRE(dqkv && qkv && inv && wq && wk && dwq && dwk && M > 0 && D > 0 && D % 64 == 0, "vtp_qk_norm_bwd: bad argument");
+  long blocks = (M * (2 * D / 8) + 255) / 256;
+  hipLaunchKernelGGL(qk_norm_bwd_kernel, dim3((int)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, (hipStream_t)stream, (bf16*)dqkv,
+                     (const bf16*)qkv, inv, wq, wk, dwq, dwk, M, D);
+  return check_launch("qk_norm_bwd");
 }

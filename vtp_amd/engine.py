@@ -424,6 +424,13 @@ class Stack:
             b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
             b.gls1 = store.g(pre + "ls1.gamma") if b.ls1 is not None else None
             b.gls2 = store.g(pre + "ls2.gamma") if b.ls2 is not None else None
+            # QK normalisation (attention.py:67-68): RMSNorm(head_dim) weights of q and k, shared by the heads
+            qn = pre + "attn.q_norm.weight"
+            if store.has(qn):
+                b.qn_w, b.kn_w = store.p(qn), store.p(pre + "attn.k_norm.weight")
+                b.g_qn, b.g_kn = store.g(qn), store.g(pre + "attn.k_norm.weight")
+            else:
+                b.qn_w = b.kn_w = b.g_qn = b.g_kn = None
             for L, gam in ((b.proj, b.ls1), (b.w3, b.ls2)):
                 if gam is not None:  # dgrad operand (gamma (.) W)^T, refreshed with the other bf16 copies
                     L.wTs = torch.empty(L.K, L.N, dtype=BF, device=store.device)
@@ -431,13 +438,14 @@ class Stack:
                         store.prep_hooks = []
                     store.prep_hooks.append(lambda L=L, gam=gam: ops.scaled_transpose(L.w32, gam, L.wTs, L.N, L.K))
             self.blocks.append(b)
+        self.qk_norm = any(b.qn_w is not None for b in self.blocks)
         self.drop_plan = None  # stochastic depth (set per step by set_drop_plan)
 
     def _rope_plan(self, ws: Workspace, segs, prefix_tokens: int, M: int):
         """(rope_pos int32 [M], sin, cos) for the fused qkv + RoPE epilogue: rope_pos[m] = row of the concatenated per-segment
         tables that rotates token row m, -1 for prefix (cls) rows.  Built once per workspace (static segment structure)."""
-        if self.style != "vit" or all(rp is None for _, _, rp in segs) or (2 * self.D) % 128:
-            return None
+        if self.style != "vit" or all(rp is None for _, _, rp in segs) or (2 * self.D) % 128 or self.qk_norm:
+            return None  # (with QK normalisation the rotation follows the norm: it cannot ride in the projection's epilogue)
         hit = getattr(ws, "_rope_plan", None)
         key = tuple((b, n, None if rp is None else rp[0].data_ptr()) for b, n, rp in segs) + (prefix_tokens,)
         if hit is not None and hit[0] == key:
@@ -499,6 +507,8 @@ class Stack:
         if plan is None:
             self.drop_plan = None
             return
+        if self.qk_norm:
+            raise NotImplementedError("stochastic depth together with QK normalisation is not built (the sample-drop branch runs the plain attention path)")
         dev = self.store.device
         cur = self.drop_plan
         if cur is None or cur["idx_dev"].numel() != plan["idx"].numel():
@@ -677,6 +687,11 @@ class Stack:
             ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
             if rope_plan is not None:  # apply_rope rides in the epilogue of the qkv projection (all segments, one launch)
                 ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, M, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+            elif b.qn_w is not None:  # projection -> QK norm (pre-norm values and 1/rms kept for the backward) -> RoPE below
+                qkv_pre = ws.get(t + "qkv_pre", (M, 3 * D), BF)
+                qinv = ws.get(t + "qinv", (M, 2 * heads), F32)
+                ops.gemm_nt(xn1, b.qkv.w, qkv_pre, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
+                ops.qk_norm_fwd(qkv_pre, b.qn_w, b.kn_w, qkv, qinv, M, D)
             else:
                 ops.gemm_nt(xn1, b.qkv.w, qkv, M=M, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
             for r0, Bs, Ns, rp in self._attn_rows(segs):
@@ -704,8 +719,8 @@ class Stack:
     # ---- fp8 (e4m3) inference forward: BASELINE config 5 (per-tensor scales: weights from their own amax, activations from a
     # calibration pass of the bf16 path over representative images)
     def fp8_begin_calibration(self):
-        if self.style != "vit" or self.D % 16 or self.H % 16 or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
-            raise NotImplementedError("fp8 forward: ViT blocks with D, H multiples of 16 and no LayerScale")
+        if self.style != "vit" or self.D % 16 or self.H % 16 or self.qk_norm or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
+            raise NotImplementedError("fp8 forward: ViT blocks with D, H multiples of 16, no LayerScale, no QK normalisation")
         dev = self.store.device
         self.fp8 = {"ready": False, "amax": torch.zeros(self.depth, 4, dtype=F32, device=dev)}
 
@@ -823,6 +838,9 @@ class Stack:
                 ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
                              dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
                              rope=rp, rope_prefix=prefix_tokens)
+            if b.qn_w is not None:  # gradient w.r.t. the normalised q, k -> w.r.t. the projection output (in place), + dw
+                ops.qk_norm_bwd(dqkv, ws.get(f"{i}.qkv_pre", (M, 3 * D), BF), ws.get(f"{i}.qinv", (M, 2 * heads), F32), b.qn_w, b.kn_w,
+                                b.g_qn, b.g_kn, M, D)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
             ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind,
                          dx_colsum=self.w3_colsum_target(i - 1) if i > 0 else None)

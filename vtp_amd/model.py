@@ -44,13 +44,17 @@ def _norm(dim: int, bias: bool) -> nn.Module:
     return m
 
 
-def _vit_block(D: int, H: int, norm: str, init_values=None) -> nn.Module:
-    """Parameter tree of SelfAttentionBlock (block.py:159-187); ls1 / ls2 = LayerScale gammas (misc.py:7-26) when `init_values`."""
+def _vit_block(D: int, H: int, norm: str, init_values=None, qk_norm: bool = False) -> nn.Module:
+    """Parameter tree of SelfAttentionBlock (block.py:159-187); ls1 / ls2 = LayerScale gammas (misc.py:7-26) when `init_values`;
+    attn.q_norm / attn.k_norm = RMSNorm(head_dim = 64) weights when `qk_norm` (attention.py:67-68)."""
     b = _holder()
     b.norm1 = _norm(D, norm != "rmsnorm")
     b.attn = _holder()
     b.attn.qkv = _linear(3 * D, D)
     b.attn.proj = _linear(D, D)
+    if qk_norm:
+        b.attn.q_norm = _norm(64, False)
+        b.attn.k_norm = _norm(64, False)
     if init_values:
         b.ls1 = _holder()
         b.ls1.gamma = _param(D)
@@ -92,7 +96,7 @@ class VTPModel(nn.Module):
         t.rope_embed = _holder()
         t.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
         Hv = swiglu_hidden(D, c.vision_mlp_ratio)
-        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer, c.vision_init_values) for _ in range(c.vision_depth)])
+        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer, c.vision_init_values, c.vision_use_qk_norm) for _ in range(c.vision_depth)])
         t.norm = _norm(D, c.vision_norm_layer != "rmsnorm")
         if c.vision_feature_bottleneck is not None and c.vision_feature_bottleneck != D:
             t.feature_bottleneck = _holder()
@@ -113,7 +117,7 @@ class VTPModel(nn.Module):
             d.rope_embed = _holder()
             d.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
             Hd = swiglu_hidden(Dd, 4.0)
-            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer, c.decoder_init_values) for _ in range(c.decoder_depth)])
+            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer, c.decoder_init_values, c.decoder_use_qk_norm) for _ in range(c.decoder_depth)])
             d.norm = _norm(Dd, c.decoder_norm_layer != "rmsnorm")
             d.proj_out = _holder()
             d.proj_out.weight = _param(768, Dd, 1, 1)
@@ -164,7 +168,7 @@ class VTPModel(nn.Module):
 
         def vit(prefix_mod):
             for name, p in prefix_mod.named_parameters():
-                if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+                if name.endswith(("norm1.weight", "norm2.weight", "q_norm.weight", "k_norm.weight")) or name == "norm.weight":
                     p.fill_(1.0)
                 elif name.endswith(".gamma"):  # LayerScale.reset_parameters (misc.py:21-22)
                     p.fill_(c.vision_init_values if prefix_mod is self.trunk else c.decoder_init_values)

@@ -224,6 +224,14 @@ def clip_loss(img_l, txt_l, img_all, txt_all, logit_scale, Bl, Bg, D, label_offs
                                      _p(scratch), _s()), "vtp_clip_loss")
 
 
+def qk_norm_fwd(qkv, wq, wk, out, inv, M, D, eps=1e-5):
+    _lib.check(_lib_().vtp_qk_norm_fwd(_p(qkv), _p(wq), _p(wk), _p(out), _p(inv), M, D, eps, _s()), "vtp_qk_norm_fwd")
+
+
+def qk_norm_bwd(dqkv, qkv, inv, wq, wk, dwq, dwk, M, D):
+    _lib.check(_lib_().vtp_qk_norm_bwd(_p(dqkv), _p(qkv), _p(inv), _p(wq), _p(wk), _p(dwq), _p(dwk), M, D, _s()), "vtp_qk_norm_bwd")
+
+
 def siglip_loss(img_l, txt_all, logit_scale, logit_bias, Bl, Bg, D, label_offset, loss_sum, d_img_l, d_txt_all, d_logit_scale,
                 d_logit_bias, scratch):
     """SigLIP (pairwise sigmoid) loss of the local images against all (gathered) texts: loss, feature gradients (local image rows
