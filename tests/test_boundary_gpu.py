@@ -271,3 +271,55 @@ def test_torch_ops_vtp_hip_callable():
     dy = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
     torch.ops.vtp_hip.gemm_tn(dy, a, dw, N, K, M, True, db)
     assert relF(dw, dy.float().T @ a.float()) < 1e-3 and relF(db, dy.float().sum(0)) < 1e-3
+
+
+def test_patch_model_rebinds_a_reference_style_instance(golden, golden_sd):
+    """vtp_amd.patch_model: an object with the reference class's surface (here: a torch module with the reference's parameter
+    names, a PretrainedConfig-like config with extra bookkeeping keys, and methods that must NOT be called afterwards) keeps its
+    identity and serves every API call from the HIP path"""
+    from oracle.ref_stubs import TINY
+    from vtp_amd import VTPConfig, VTPModel, patch_model
+
+    class Cfg:
+        def __init__(self, d):
+            self.d = d
+
+        def to_dict(self):
+            return dict(self.d, transformers_version="4.x", model_type="vtp", architectures=["VTPModel"])
+
+    class RefLike(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = Cfg(VTPConfig(**TINY).to_dict())
+            self.holder = torch.nn.ParameterDict()  # flat storage under the reference's key names
+            self._sd = {k: v.clone() for k, v in golden_sd.items()}
+
+        def state_dict(self, *a, **k):
+            return self._sd
+
+        def get_reconstruction_latents(self, image):
+            raise AssertionError("the reference path must not run after patch_model")
+
+        def forward(self, *a, **k):
+            raise AssertionError("the reference path must not run after patch_model")
+
+    ref = RefLike().eval()
+    out = patch_model(ref)
+    assert out is ref and isinstance(ref._vtp_amd, VTPModel) and not ref._vtp_amd.training
+    img, txt = golden["in.image"].to(DEV), golden["in.text"].to(DEV)
+    direct = VTPModel(VTPConfig(**TINY))
+    direct.load_state_dict(golden_sd)
+    direct = direct.to(DEV).eval()
+    with torch.no_grad():
+        lat = ref.get_reconstruction_latents(img)
+        assert torch.equal(lat, direct.get_reconstruction_latents(img))
+        assert torch.equal(ref.get_latents_decoded_images(lat), direct.get_latents_decoded_images(lat))
+        assert torch.equal(ref.get_clip_text_feature(txt), direct.get_clip_text_feature(txt))
+        r1, r2 = ref(image=img, forward_type="rec"), direct(image=img, forward_type="rec")
+        assert set(r1) == set(r2) and torch.equal(r1["reconstructed_image"], r2["reconstructed_image"])
+    assert set(dict(ref.named_parameters())) == set(dict(direct.named_parameters()))
+    ref.train()
+    assert ref._vtp_amd.training
+    loss = (ref.get_latents_decoded_images(ref.get_reconstruction_latents(img)) - img).abs().mean()
+    loss.backward()  # differentiable through the patched object
+    assert float(dict(ref.named_parameters())["trunk.blocks.0.attn.qkv.weight"].grad.abs().sum()) > 0

@@ -216,3 +216,16 @@ def test_qk_norm_branch_matches_reference():
     for k in ("trunk.blocks.0.attn.q_norm.weight", "trunk.blocks.1.attn.k_norm.weight", "pixel_decoder.blocks.0.attn.q_norm.weight",
               "trunk.blocks.0.attn.qkv.weight"):
         torch.testing.assert_close(sd[k].grad, params[k].grad, rtol=2e-3, atol=1e-6)
+
+
+def test_patch_model_config_and_keys_against_the_real_class(ref_model):
+    """the host half of vtp_amd.patch_model on the REAL reference instance: its PretrainedConfig translates to our VTPConfig and
+    its state_dict loads strict=True into our parameter tree (the device half runs in tests/test_boundary_gpu.py)"""
+    from vtp_amd import VTPModel
+    from vtp_amd.patch import API_METHODS, _our_config
+    cfg = _our_config(ref_model.config)
+    assert cfg.vision_embed_dim == ref_model.config.vision_embed_dim and cfg.vision_depth == ref_model.config.vision_depth
+    ours = VTPModel(cfg)
+    ours.load_state_dict({k: v.detach() for k, v in ref_model.state_dict().items()}, strict=True)
+    for name in API_METHODS:
+        assert callable(getattr(ref_model, name)) and callable(getattr(ours, name)), name

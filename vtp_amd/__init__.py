@@ -19,6 +19,9 @@ def __getattr__(name):  # lazy: importing the package must not require torch.cud
     if name == "VTP_Tokenizer":
         from .tokenizer import VTP_Tokenizer
         return VTP_Tokenizer
+    if name == "patch_model":
+        from .patch import patch_model
+        return patch_model
     if name == "VTPTrainer":
         from .train import VTPTrainer
         return VTPTrainer
