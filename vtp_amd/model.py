@@ -493,13 +493,17 @@ class VTPModel(nn.Module):
         return f.clone()
 
     def get_clip_logits(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """modeling_vtp.py:312-333 (the [B_img, B_txt] logits GEMM is host-level glue on two small normalised matrices)."""
+        """modeling_vtp.py:312-333.  Inference: the [B_img, B_txt] logits come from the clip_logits kernel (exp(logit_scale) * I T^T,
+        fp32); in training mode they are torch ops on the two differentiable feature matrices (autograd needs them on the tape)."""
         i = self.get_clip_image_feature(image, normalize=True)
         t = self.get_clip_text_feature(text, normalize=True)
-        with torch.set_grad_enabled(ag.grad_mode(self)):
+        if ag.grad_mode(self):
             logits = self.logit_scale.exp() * i @ t.T
-            if self.logit_bias is not None:
-                logits = logits + self.logit_bias
+        else:
+            logits = torch.empty(i.shape[0], t.shape[0], dtype=torch.float32, device=i.device)
+            ops.clip_logits(i.contiguous(), t.contiguous(), self._store.p("logit_scale"), logits, i.shape[0], t.shape[0], i.shape[1])
+        if self.logit_bias is not None:
+            logits = logits + self.logit_bias
         return logits, logits.T
 
     def forward(self, image=None, text=None, forward_type: str = "clip"):

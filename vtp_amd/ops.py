@@ -232,6 +232,11 @@ def qk_norm_bwd(dqkv, qkv, inv, wq, wk, dwq, dwk, M, D):
     _lib.check(_lib_().vtp_qk_norm_bwd(_p(dqkv), _p(qkv), _p(inv), _p(wq), _p(wk), _p(dwq), _p(dwk), M, D, _s()), "vtp_qk_norm_bwd")
 
 
+def clip_logits(a, b, logit_scale, out, M, N, D):
+    """out f32 [M, N] = exp(logit_scale) * a[M, D] @ b[N, D]^T  (the logits of modeling_vtp.py:326-329)"""
+    _lib.check(_lib_().vtp_clip_logits(_p(a), _p(b), _p(logit_scale), _p(out), M, N, D, _s()), "vtp_clip_logits")
+
+
 def siglip_loss(img_l, txt_all, logit_scale, logit_bias, Bl, Bg, D, label_offset, loss_sum, d_img_l, d_txt_all, d_logit_scale,
                 d_logit_bias, scratch):
     """SigLIP (pairwise sigmoid) loss of the local images against all (gathered) texts: loss, feature gradients (local image rows
