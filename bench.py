@@ -415,7 +415,7 @@ def main():
     roof = None
     recs = []
     import vtp_amd.engine as eng
-    orig_nt, orig_tn, orig_qkv = ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope
+    orig_nt, orig_tn, orig_qkv, orig_dsw = ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu
 
     def timed(fn):
         def run(a, b, c, **kw):
@@ -436,8 +436,15 @@ def main():
         e1.record()
         recs.append((2.0 * M * N * K, e0, e1, ("gemm_qkv_rope", M, N, K, 0, 1)))
 
+    def timed_dsw(dy, wT, x12, dx12, M, H, K):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_dsw(dy, wT, x12, dx12, M, H, K)
+        e1.record()
+        recs.append((2.0 * M * H * K, e0, e1, ("gemm_dgrad_swiglu", M, H, K, 0, 1)))
+
     if rank == 0:
-        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope = timed(orig_nt), timed(orig_tn), timed_qkv
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = timed(orig_nt), timed(orig_tn), timed_qkv, timed_dsw
     trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
     overlap_was = eng.OVERLAP.enabled
     eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
@@ -445,7 +452,7 @@ def main():
         trainer.step(img, txt, ssl)  # every rank takes the step (it contains the collectives); rank 0 times its GEMMs
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope = orig_nt, orig_tn, orig_qkv
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = orig_nt, orig_tn, orig_qkv, orig_dsw
         eng.OVERLAP.enabled = overlap_was
     if rank == 0:
         fl = sum(r[0] for r in recs)

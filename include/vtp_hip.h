@@ -171,6 +171,9 @@ int vtp_prep_weights(const void* descs, int n, int total_tiles, void* stream);
 /* SwiGLU backward (ffn.py:80): given dh bf16 [M,H] and saved x12 bf16 [M,2H] (interleaved 8|8), writes dx12 bf16 [M,2H].
  * db12 (optional, f32 [2H] = [b1 | b2], accumulated): column sums of dx12 = the bias gradients of w1 / w2. */
 int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float* db12, int M, int H, void* stream);
+/* the same backward fused into the w3 dgrad GEMM: dx12[M, 2H] from dy[M, K] W3^T[H, K]^T and the saved x12 -- dh never reaches HBM */
+int vtp_gemm_dgrad_swiglu(const void* A, int lda, const void* WT, int ldb, const void* x12, int ldx, void* dx12, int ldc, int M, int H,
+                          int K, void* stream);
 /* GELU backward (text MLP, block.py:399): dx = dy * gelu'(pre). */
 int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream);
 

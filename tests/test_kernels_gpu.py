@@ -596,3 +596,21 @@ def test_gemm_qkv_rope_bit_identical_to_gemm_then_rope(cfg):
         lib.vtp_set_gemm_tuning(-1, 3)
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
         f"cfg {cfg}: {int((out.view(torch.int16) != ref.view(torch.int16)).sum())} elements differ"
+
+
+@pytest.mark.parametrize("M,H,D", [(8192, 2048, 768), (2500, 344 - 344 % 8, 128), (16448, 2048, 768), (130, 1024, 384)])
+def test_gemm_dgrad_swiglu_fused_equals_two_kernels(M, H, D):
+    """w3 dgrad with swiglu_bwd in its epilogue == vtp_gemm_nt (bf16 dh) followed by vtp_swiglu_bwd, bit for bit (the fused epilogue
+    rounds dh to bf16 at the same point), on the 8-phase and on the ring tile configurations, with row / column tails"""
+    from vtp_amd import ops
+    torch.manual_seed(M + H)
+    dy = (torch.randn(M, D, device=DEV) * 0.5).to(torch.bfloat16)
+    wT = (torch.randn(H, D, device=DEV) * 0.05).to(torch.bfloat16)
+    x12 = torch.randn(M, 2 * H, device=DEV).to(torch.bfloat16)
+    dh = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    ref = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(dy, wT, dh, M=M, N=H, K=D, epi=ops.EPI_BF16)
+    ops.swiglu_bwd(dh, x12, ref, M, H)
+    out = torch.full((M, 2 * H), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_dgrad_swiglu(dy, wT, x12, out, M, H, D)
+    assert torch.equal(out, ref)

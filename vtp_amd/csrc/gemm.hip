@@ -542,6 +542,25 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   return VTP_OK;
 }
 
+// w3 dgrad with the SwiGLU backward in its epilogue (ffn.py:78-81 backward): dh = dy W3 is formed per tile and leaves as
+// dx12[M, 2H] = d(silu(x1) x2)/d(x1 | x2) (.) dh with x12 the saved pre-activations (interleaved 8 | 8 like the forward's w12
+// output) -- one launch and no dh round trip instead of vtp_gemm_nt + vtp_swiglu_bwd.  A = dy bf16 [M, K = D], WT = W3^T bf16 [H, D].
+extern "C" int vtp_gemm_dgrad_swiglu(const void* A, int lda, const void* WT, int ldb, const void* x12, int ldx, void* dx12, int ldc,
+                                     int M, int H, int K, void* stream) {
+  VTP_REQUIRE(A && WT && x12 && dx12, "vtp_gemm_dgrad_swiglu: null operand");
+  VTP_REQUIRE(M > 0 && H > 0 && K > 0 && H % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 8 == 0 && ldc % 8 == 0 &&
+              ldx >= 2 * H && ldc >= 2 * H, "vtp_gemm_dgrad_swiglu: H, K and the leading dimensions must be multiples of 8, ldx / ldc >= 2 H");
+  VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)WT % 16 == 0) && ((uintptr_t)x12 % 16 == 0) && ((uintptr_t)dx12 % 16 == 0),
+              "vtp_gemm_dgrad_swiglu: operands must be 16-B aligned");
+  GemmArgs a{};
+  a.A = (const bf16*)A; a.B = (const bf16*)WT; a.C = dx12;
+  a.M = M; a.N = H; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.alpha = 1.f;
+  a.xcd_swizzle = swz_flags() | 2;  // the fused backward lives in the LDS-staged store path
+  a.k_split = (K + 63) / 64 * 64;
+  a.swiglu_pre = (const bf16*)x12; a.swiglu_ld = ldx;
+  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg(M, H, K, VTP_EPI_BF16, 1), (hipStream_t)stream);
+}
+
 // fp8 (e4m3, OCP) forward GEMM (BASELINE config 5): C = alpha * (A8 B8^T) (+ bias, + residual / SwiGLU), A8 [M, K] and B8 [N, K]
 // row-major bytes, alpha = 1 / (scale_a * scale_b) of the per-tensor quantisation.  Runs the 256 x 256 8-phase kernel with the
 // 32x32x64 f8f6f4 MFMA; K and the leading dimensions are in fp8 elements and multiples of 16 here.

@@ -38,6 +38,12 @@ struct GemmArgs {
   // TRANS (weight-gradient) mode: if non-null, the column sums of A over the reduction rows (= the bias gradient of the linear
   // layer, db[m] = sum_t dy[t, m]) are ACCUMULATED into colsum[remap_row(m, c_grp, c_pre)] by the kernels that support it
   float* colsum;
+  // fused SwiGLU backward in the bf16 epilogue of the w3 dgrad GEMM (ffn.py:78-81 backward): the GEMM result is dh [M, N = H]; with
+  // swiglu_pre = the saved pre-activations x12 bf16 [M, 2N] (16-column groups = 8 of x1 | 8 of x2, row stride swiglu_ld) the
+  // epilogue writes dx12 = d(silu(x1) x2)/d(x12) (.) dh into C as [M, 2N] (row stride ldc) and dh itself never reaches HBM.
+  // null: plain epilogue.
+  const bf16* swiglu_pre;
+  int swiglu_ld;
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
@@ -121,6 +127,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
               for (int e = 0; e < 8; ++e)
                 val[e] = f2bf(bf2f(f2bf(bf2f(val[e]) * bf2f(cs[e]))) + bf2f(f2bf(sg * bf2f(prt[e]) * bf2f(sn[e]))));
             }
+          }
+          if (p.swiglu_pre) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
+            if (m < p.M && n < p.N) {
+              const bf16* xr = p.swiglu_pre + (size_t)m * p.swiglu_ld + 2 * n;
+              const bf16x8 x1 = *(const bf16x8*)xr, x2 = *(const bf16x8*)(xr + 8);
+              bf16x8 o1, o2;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float a = bf2f(x1[e]), b = bf2f(x2[e]), gd = bf2f(val[e]);
+                const float sg = sigmoid_f(a);
+                const float gs = bf2f(f2bf(gd * b));
+                o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));
+                o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));
+              }
+              bf16* orow = (bf16*)p.C + (size_t)m * p.ldc + 2 * n;
+              *(bf16x8*)orow = o1;
+              *(bf16x8*)(orow + 8) = o2;
+            }
+            continue;
           }
           if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
         }

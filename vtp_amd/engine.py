@@ -263,6 +263,7 @@ class Overlap:
 
 OVERLAP = Overlap()
 FUSE_COLSUM = _env_flag("VTP_FUSE_COLSUM")  # bias gradients inside the weight-gradient GEMM (0: separate column-sum launches)
+FUSE_SWIGLU_BWD = _env_flag("VTP_FUSE_SWIGLU_BWD")  # swiglu_bwd in the epilogue of the w3 dgrad GEMM (0: separate elementwise launch)
 FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
 WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
@@ -282,7 +283,7 @@ def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
                x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0,
-               bias_grad_done: bool = False, ls=None):
+               bias_grad_done: bool = False, ls=None, dgrad_swiglu=None):
     """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
     column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
@@ -365,7 +366,12 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
     else:
         OVERLAP.join()
         wgrad()
-    if need_dx:
+    if need_dx and dgrad_swiglu is not None:
+        # this linear is the w3 of a SwiGLU FFN: the dgrad GEMM's epilogue applies the activation backward with the saved x12 and
+        # writes dx12 directly (d_in = the [M, 2K] pre-activation gradient); dh never exists in HBM
+        assert dy_remap == (0, 0) and dx_remap == (0, 0)
+        ops.gemm_dgrad_swiglu(dy_b, wT, dgrad_swiglu, d_in, M, K, N)
+    elif need_dx:
         ops.gemm_nt(dy_b, wT, d_in, M=M, N=K, K=N, lda=dy_b.stride(0), ldb=N, ldc=d_in.stride(0), epi=EPI_BF16,
                     a_remap=dy_remap, c_remap=dx_remap)
 
@@ -811,14 +817,16 @@ class Stack:
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
             # ---- FFN: x_out = x_mid + w3(act(...))
-            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dh,
+            fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1"
+            fused_act = vit and FUSE_SWIGLU_BWD and b.ls2 is None and not fuse
+            linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dpre if fused_act else dh,
                        bias_grad_done=dy_colsum_done if i == self.depth - 1 else self.w3_colsum_target(i) is not None,
-                       ls=(b.ls2, b.gls2) if b.ls2 is not None else None)
+                       ls=(b.ls2, b.gls2) if b.ls2 is not None else None, dgrad_swiglu=pre if fused_act else None)
             if vit:
-                # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
-                # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
-                fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1"
-                ops.swiglu_bwd(dh, pre, dpre, M, H, db12=b.w12.gb1 if fuse else None)
+                if not fused_act:
+                    # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
+                    # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
+                    ops.swiglu_bwd(dh, pre, dpre, M, H, db12=b.w12.gb1 if fuse else None)
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
                            swiglu_h=H, bias_grad_done=fuse)
             else:

@@ -232,6 +232,12 @@ def qk_norm_bwd(dqkv, qkv, inv, wq, wk, dwq, dwk, M, D):
     _lib.check(_lib_().vtp_qk_norm_bwd(_p(dqkv), _p(qkv), _p(inv), _p(wq), _p(wk), _p(dwq), _p(dwk), M, D, _s()), "vtp_qk_norm_bwd")
 
 
+def gemm_dgrad_swiglu(dy, wT, x12, dx12, M, H, K):
+    """dx12[M, 2H] = SwiGLU'(x12) (.) (dy[M, K] @ wT[H, K]^T): the w3 dgrad with swiglu_bwd in its epilogue"""
+    _lib.check(_lib_().vtp_gemm_dgrad_swiglu(_p(dy), dy.stride(0), _p(wT), wT.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0),
+                                             M, H, K, _s()), "vtp_gemm_dgrad_swiglu")
+
+
 def clip_logits(a, b, logit_scale, out, M, N, D):
     """out f32 [M, N] = exp(logit_scale) * a[M, D] @ b[N, D]^T  (the logits of modeling_vtp.py:326-329)"""
     _lib.check(_lib_().vtp_clip_logits(_p(a), _p(b), _p(logit_scale), _p(out), M, N, D, _s()), "vtp_clip_logits")
