@@ -91,8 +91,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int RB = WTN * 2, CPR = RB / 16;
       static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
       const int r = lane & 31;
+      constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
+        // fused SwiGLU backward: this block's x1 | x2 pre-activations are requested BEFORE the accumulators go through LDS, so the
+        // loads fly while the block is transposed (they are consumed in the store loop below)
+        bf16x8 sx1[TPB], sx2[TPB];
+        if (p.swiglu_pre) {
+#pragma unroll
+          for (int t = 0; t < TPB; ++t) {
+            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+            const int m = min(m0 + wm * WTM + j * 32 + rr, p.M - 1), n = min(n0 + wn * WTN + c * 8, p.N - 8);
+            const bf16* xr = p.swiglu_pre + (size_t)m * p.swiglu_ld + 2 * n;
+            sx1[t] = *(const bf16x8*)xr;
+            sx2[t] = *(const bf16x8*)(xr + 8);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -105,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
           }
 #pragma unroll
-        for (int t = 0; t < 32 * CPR / 64; ++t) {
+        for (int t = 0; t < TPB; ++t) {
           const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
           bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
           const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
@@ -130,8 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           }
           if (p.swiglu_pre) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
             if (m < p.M && n < p.N) {
-              const bf16* xr = p.swiglu_pre + (size_t)m * p.swiglu_ld + 2 * n;
-              const bf16x8 x1 = *(const bf16x8*)xr, x2 = *(const bf16x8*)(xr + 8);
+              const bf16x8 x1 = sx1[t], x2 = sx2[t];
               bf16x8 o1, o2;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
