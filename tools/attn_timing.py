@@ -1,3 +1,5 @@
+"""In-kernel phase stamps of the resident attention forward (s_memtime at: first data, barrier, end of the key loop, stores, odd-tile
+share, merge) for one workgroup: VTP_ATTN_TIMING=1 AT_B=<images> python tools/attn_timing.py   (prints cycle counts per wave)."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch

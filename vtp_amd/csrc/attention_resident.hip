@@ -9,7 +9,9 @@
 // in the GEMM, and bit 2 alternates between rows r and r+2, so the four rows x 64 B of a ds_read_b64_tr_b16 half-wave land on
 // disjoint bank quarters.  The image is filled by LDS-DMA (global_load_lds_dwordx4), the swizzle applied on the source side.
 //
-// Forward is two-pass over the resident keys (row maximum first, then exp / sum / PV): no running rescale of the accumulator.
+// Forward: attn_fwd_res2_kernel (default: two query tiles per wave, single-pass online softmax, K / V streamed behind the key
+// loop, odd last tile split over the waves); attn_fwd_res_kernel is the round-1 two-pass variant (VTP_ATTN_V2=0, and shapes the
+// v2 work split does not cover).  Backward: dQ and dK/dV kernels with delta and the inverse RoPE fused.
 #include "common.h"
 #include <algorithm>
 #include <cstdio>
@@ -236,10 +238,6 @@ __global__ __launch_bounds__(640) void attn_fwd_res_kernel(const AttnResArgs p) 
 // that tile against a quarter of the key blocks, and the partial (max, sum, O) are merged through a few hundred bytes of LDS
 // (split-K over the keys, only the valid columns travel).  4 waves x <= 256 VGPRs and 74 KB of LDS: two workgroups share a CU,
 // one's staging / stores under the other's key loop.
-__device__ __forceinline__ float both_halves_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 __device__ __forceinline__ float both_halves_sum(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
