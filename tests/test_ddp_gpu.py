@@ -121,3 +121,73 @@ def test_sharded_optimizer_matches_allreduce(golden_sd, use_graphs, grad_dtype):
     assert rel_m < (1e-4 if grad_dtype == "fp32" else 1e-2)  # fp32: summation order (fused bias-gradient atomics) only
     for a, b in zip(res[True][0], res[False][0]):
         assert abs(a[0] - b[0]) < 1e-4 * abs(b[0]) + 1e-6
+
+
+def _ssl_batch(B=4, n_local=4, R=64, r=32):
+    g = torch.Generator().manual_seed(11)
+    glob = torch.randn(2 * B, 3, R, R, generator=g)            # view-major: [view 0 images | view 1 images]
+    loc = torch.randn(n_local * B, 3, r, r, generator=g)       # crop-major: index = crop * B + image
+    masks = torch.rand(2 * B, (R // 16) ** 2, generator=g) < 0.3
+    masks[1] = False                                            # an image without masked patches
+    img = torch.randn(B, 3, R, R, generator=g)
+    return img, glob, loc, masks
+
+
+def _ssl_shard(rank, world, B, n_local, img, glob, loc, masks):
+    bl = B // world
+    ids = torch.arange(rank * bl, (rank + 1) * bl)
+    gi = torch.cat([ids, B + ids])
+    li = torch.cat([j * B + ids for j in range(n_local)])
+    return img[ids], glob[gi], loc[li], masks[gi]
+
+
+def _ssl_worker(rank, world, port, centering, out):
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import torch.distributed as dist
+    from safetensors.torch import load_file
+    from vtp_amd import VTPTrainer
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("_ssl_t", os.path.join(ROOT, "tests", "test_ssl_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = load_file(os.path.join(ROOT, "tests", "golden", "vtp_tiny_ssl.safetensors"))
+    torch.manual_seed(0)  # the towers the SSL golden does not cover (decoder, text) are random-initialised: same seed everywhere
+    m = mod.build_vtp({k[3:]: v for k, v in g.items() if k.startswith("sd.")})
+    tr = VTPTrainer(m, lr=1e-3, weight_decay=0.0, centering=centering, bucket_blocks=1, use_graphs=True)  # every rank must use the same driver: the graph driver's eager warm-up step runs the collectives too
+    B, n_local = 4, 4
+    img, glob, loc, masks = _ssl_shard(rank, world, B, n_local, *_ssl_batch(B, n_local))
+    losses = []
+    for i in range(2):
+        ssl = tr.prepare_ssl(glob.cuda(), loc.cuda(), masks, upperbound=int(0.5 * masks.numel()))
+        tr.step(img.cuda(), None, ssl)
+        losses.append(float(tr.ssl_loss_sum))
+    torch.cuda.synchronize()
+    out[rank] = (losses, m._engine().flat_p.detach().cpu().clone(), tr.center_dino.cpu().clone())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("centering", ["softmax", "sinkhorn_knopp"])
+def test_two_ranks_ssl_step_matches_single_process(centering):
+    """rec + DINO/iBOT step, 2 ranks x 2 images vs 1 process x 4 images: gradient buckets, the centre statistics all-reduce (softmax
+    centring) or the phased Sinkhorn-Knopp all-reduces, EMA teacher -- same weights and centres afterwards"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = {}
+    for world in (1, 2):
+        out = mp.Manager().dict()
+        mp.spawn(_ssl_worker, args=(world, _free_port(), centering, out), nprocs=world, join=True)
+        res[world] = dict(out)
+    l1, p1, c1 = res[1][0]
+    (la, pa, ca), (lb, pb, cb) = res[2][0], res[2][1]
+    assert torch.equal(pa, pb) or float((pa - pb).norm() / pa.norm()) < 1e-6, "ranks diverged"
+    rel = float((pa - p1).norm() / p1.norm())
+    print(f"[{centering}] single {l1} rank0 {la} rank1 {lb}; weights rel {rel:.3e}; centre rel {float((ca - c1).norm() / (c1.norm() + 1e-30)):.3e}")
+    for i in range(2):
+        assert abs(0.5 * (la[i] + lb[i]) - l1[i]) < 2e-3 * abs(l1[i])
+    assert rel < 5e-4
+    if centering == "softmax":
+        assert float((ca - c1).norm() / c1.norm()) < 1e-3 and torch.equal(ca, cb)
