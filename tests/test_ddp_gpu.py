@@ -21,11 +21,11 @@ def _free_port():
     return p
 
 
-def _build(golden_sd):
+def _build(golden_sd, siglip=False):
     from oracle.ref_stubs import TINY
     from vtp_amd import VTPConfig, VTPModel
-    m = VTPModel(VTPConfig(**TINY))
-    m.load_state_dict(golden_sd, strict=True)
+    m = VTPModel(VTPConfig(**dict(TINY, init_logit_bias=-3.0) if siglip else VTPConfig(**TINY).to_dict()))
+    m.load_state_dict(golden_sd, strict=not siglip)
     return m.to("cuda:0")
 
 
@@ -38,7 +38,7 @@ def _data():
     return img, txt
 
 
-def _worker(rank, world, port, use_graphs, out, shard=False, grad_dtype="fp32"):
+def _worker(rank, world, port, use_graphs, out, shard=False, grad_dtype="fp32", siglip=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from safetensors.torch import load_file
@@ -47,7 +47,7 @@ def _worker(rank, world, port, use_graphs, out, shard=False, grad_dtype="fp32"):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = load_file(os.path.join(ROOT, "tests", "golden", "vtp_tiny.safetensors"))
     sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
-    m = _build(sd)
+    m = _build(sd, siglip)
     tr = VTPTrainer(m, lr=1e-3, weight_decay=0.01, use_graphs=use_graphs, bucket_blocks=1, shard_optimizer=shard,
                     grad_dtype=grad_dtype)
     tr.time_comm = True
@@ -191,3 +191,28 @@ def test_two_ranks_ssl_step_matches_single_process(centering):
     assert rel < 5e-4
     if centering == "softmax":
         assert float((ca - c1).norm() / c1.norm()) < 1e-3 and torch.equal(ca, cb)
+
+
+
+def test_two_ranks_siglip_matches_single_process(golden_sd):
+    """SigLIP under data parallelism: every (local image, any rank's text) pair counted once, text gradients returned by
+    reduce-scatter -- 2 ranks x 2 pairs == 1 process x 4 pairs"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vtp_amd import VTPTrainer
+    m = _build(golden_sd, siglip=True)
+    tr = VTPTrainer(m, lr=1e-3, weight_decay=0.01)
+    img, txt = _data()
+    ref_losses = [tuple(float(x) for x in tr.step((img + 0.01 * i).cuda(), txt.cuda())) for i in range(3)]
+    ref_p = m._engine().flat_p.detach().cpu().clone()
+    del tr, m
+    torch.cuda.empty_cache()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), False, out, False, "fp32", True), nprocs=2, join=True)
+    (l0, p0, _), (l1, p1, _) = out[0], out[1]
+    rel = float((p0 - ref_p).norm() / ref_p.norm())
+    print("siglip single:", ref_losses, "rank0:", l0, "rank1:", l1, f"weights rel {rel:.3e}")
+    assert torch.equal(p0, p1)
+    for i in range(3):
+        assert abs(0.5 * (l0[i][1] + l1[i][1]) - ref_losses[i][1]) < 5e-3 * abs(ref_losses[i][1])
+    assert rel < 2e-4
