@@ -110,6 +110,52 @@ def test_bucketed_allreduce_world2_gloo():
         assert torch.equal(out[r], exp)
 
 
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vtp_amd.train import GradBucketer
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n = 100
+    flat_g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    flat_p = torch.zeros(n)
+    gb = GradBucketer(flat_g, shard=True)
+    ranges = [(4, 44), (60, 100)]          # 40 elements each: chunks of 16 (8-aligned) -> the last chunk is partly padding
+    for lo, hi in ranges:
+        gb.reduce_scatter_range(lo, hi)
+    gb.wait()
+    recs = [gb._rec(lo, hi) for lo, hi in ranges]
+    own = []
+    for rec in recs:                        # "optimizer" on the own chunk: p = -g_sum
+        k = rec.b - rec.a
+        own.append((rec.a, rec.b))
+        flat_p[rec.a:rec.b] = -rec.g32[:k]
+        rec.p_send.zero_()
+        rec.p_send[:k] = flat_p[rec.a:rec.b]
+    gb.all_gather_params(flat_p, recs)
+    for rec in recs:
+        flat_p[rec.lo:rec.hi] = rec.p_recv[:rec.hi - rec.lo]
+    out[rank] = (flat_p.clone(), own, [r.chunk for r in recs])
+    dist.destroy_process_group()
+
+
+def test_sharded_bucket_exchange_world2_gloo():
+    """reduce-scatter + own-chunk update + all-gather of the sharded optimizer (train.GradBucketer) on CPU tensors: every rank ends
+    with the full updated buffer, ownership is disjoint and covers each bucket, chunks are 8-element aligned"""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_shard_worker, args=(world, port, out), nprocs=world, join=True)
+    base = torch.arange(100, dtype=torch.float32)
+    exp = torch.zeros(100)
+    for lo, hi in ((4, 44), (60, 100)):
+        exp[lo:hi] = -3 * base[lo:hi]
+    for r in range(world):
+        assert torch.equal(out[r][0], exp), r
+        assert all(c % 8 == 0 for c in out[r][2])
+    for i, (lo, hi) in enumerate(((4, 44), (60, 100))):
+        (a0, b0), (a1, b1) = out[0][1][i], out[1][1][i]
+        assert a0 == lo and b0 == a1 and b1 == hi  # disjoint cover in rank order
+
+
 def test_ssl_index_plan_matches_reference_buffer_layout():
     """build_ssl_indices (host): teacher cls rows are view-swapped (vtp.py:425-426), masked patch rows address the
     [B, 1+hw, D] stream, per-image iBOT weights are 1 / n_masked(image), padding rows are inert."""
