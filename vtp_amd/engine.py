@@ -262,7 +262,11 @@ class Overlap:
 
 
 OVERLAP = Overlap()
-FUSE_COLSUM = _env_flag("VTP_FUSE_COLSUM")  # bias gradients inside the weight-gradient GEMM (0: separate column-sum launches)
+# bias gradients inside the weight-gradient GEMM (VTP_FUSE_COLSUM=1) or as separate column-sum launches on the wgrad side stream
+# (default).  Same-box A/B of the final round-2 build: the in-kernel sums (v_dot2 on the A fragments + one fp32 atomic per row, tile
+# and split) are neutral on the 34 k-row full step (582 / 578 vs 587 / 577 images/s) and cost 2.7 % on the VTP-B rec-only step and
+# 20 % on VTP-S rec at batch 64 (short K slices, many splits hammering the same 384 addresses)
+FUSE_COLSUM = _env_flag("VTP_FUSE_COLSUM", "0")
 FUSE_SWIGLU_BWD = _env_flag("VTP_FUSE_SWIGLU_BWD")  # swiglu_bwd in the epilogue of the w3 dgrad GEMM (0: separate elementwise launch)
 FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
 # weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
