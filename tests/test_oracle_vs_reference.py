@@ -229,3 +229,27 @@ def test_patch_model_config_and_keys_against_the_real_class(ref_model):
     ours.load_state_dict({k: v.detach() for k, v in ref_model.state_dict().items()}, strict=True)
     for name in API_METHODS:
         assert callable(getattr(ref_model, name)) and callable(getattr(ours, name)), name
+
+
+@pytest.mark.parametrize("clip_feat,ae_only", [("pooled", True), ("cls", False), ("pooled", False)])
+def test_clip_image_feature_variants_match_reference(clip_feat, ae_only):
+    """vision_clip_feat='pooled' (mean of the patch tokens, modeling_vtp.py:269) and vision_bottleneck_ae_only=False (the CLIP
+    head sees the bottlenecked features, :252-262) -- the oracle branches behind vtp_amd's torch-head path -- plus the SigLIP
+    logit bias (:330-331)"""
+    ns = load_reference()
+    torch.manual_seed(7)
+    cfg = dict(TINY)
+    cfg.update(image_size=64, vision_clip_feat=clip_feat, vision_bottleneck_ae_only=ae_only, init_logit_bias=-2.5)
+    m = ns.VTPModel(ns.VTPConfig(**cfg)).eval()
+    sd = m.state_dict()
+    img = torch.randn(2, 3, 64, 64)
+    text = torch.randint(1, 500, (2, 16))
+    text[:, 9] = 511
+    with torch.no_grad():
+        f_ref = m.get_clip_image_feature(img)
+        f = O.clip_image_feature(sd, img, 2, clip_feat=clip_feat, ae_only=ae_only)
+        torch.testing.assert_close(f, f_ref, rtol=1e-4, atol=1e-5)
+        li, _ = m.get_clip_logits(img, text)
+        t = O.clip_text_feature(sd, text, 2)
+        lo = sd["logit_scale"].exp() * f @ t.T + sd["logit_bias"]
+        torch.testing.assert_close(lo, li, rtol=1e-4, atol=1e-4)
