@@ -309,3 +309,22 @@ def test_latent_shard_writer_layout(tmp_path):
         assert f.metadata() == {"total_size": "2", "dtype": "torch.float32", "device": "cpu"}
     with pytest.raises(ValueError):
         LatentShardWriter(str(tmp_path), batch_size=20000)
+
+
+def test_bench_flop_accounting_matches_survey():
+    """bench.py's algorithmic-FLOP helpers against the per-image forward GFLOP table of SURVEY.md §8(d) / BASELINE.md §4"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from vtp_amd.config import swiglu_hidden
+    hw = 256
+    rows = {"S": (384, 12, 12.30, 12.24, 3.38), "B": (768, 12, 46.42, 46.23, 13.30), "L": (1024, 24, 162.35, 161.70, 47.09)}
+    for name, (D, L, enc, dec, txt) in rows.items():
+        H = swiglu_hidden(D)
+        assert abs(b.vit_fwd_gflop(D, H, L, hw + 1, hw, True) - enc) < 0.02 * enc, name
+        assert abs(b.vit_fwd_gflop(D, H, L, hw, hw, False) - dec) < 0.02 * dec, name
+        assert abs(b.text_fwd_gflop(D, L, 77) - txt) < 0.02 * txt, name
+    assert abs(b.vit_fwd_gflop(1024, swiglu_hidden(1024), 24, 1025, 1024, True) - 724.91) < 0.02 * 724.91
+    assert abs(3 * (46.42 + 46.23) - 277.9) < 0.1  # the rec-only train-step figure the bench's step_frac is built on
+    assert set(b.WORKLOADS) >= {"vtp_base_full", "vtp_small_rec", "vtp_large_full_512"} and "vtp_large_fp8_fwd" in b.FORWARD_WORKLOADS
