@@ -63,6 +63,10 @@ int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
+/* diagnostics (tools/gemm8p_timeline.py): `timing` = device buffer of [workgroups][16 tiles][4] 64-bit s_memrealtime stamps
+ * {tile start, k loop done, epilogue issued} written by the 256x256 kernel (null = off); grid_limit caps its persistent grid
+ * (0 = every CU).  Process-global; not part of the reference-facing surface. */
+int vtp_gemm_debug(void* timing, int grid_limit);
 int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);

@@ -214,7 +214,10 @@ def _attn_ref(q, k, v, causal):
 
 
 @pytest.mark.parametrize("B,N,heads,causal", [(2, 257, 3, False), (1, 256, 2, False), (3, 17, 2, False), (2, 77, 2, True),
-                                              (1, 1025, 2, False), (2, 130, 1, True), (1, 64, 1, False)])
+                                              (1, 1025, 2, False), (2, 130, 1, True), (1, 64, 1, False),
+                                              # the launches of the benchmarked list forward (VTP-B, 12 heads): local 96^2 crops
+                                              # (N = 37) and the merged clean-image + global-crop segment (32 + 64 images, N = 257)
+                                              (16, 37, 12, False), (96, 257, 12, False)])
 def test_attention_fwd_bwd(B, N, heads, causal):
     o = ops()
     D = heads * 64

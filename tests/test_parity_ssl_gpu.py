@@ -1,0 +1,215 @@
+"""Parity of the SELF-SUPERVISED leg at the configuration bench.py times: VTP-Base trunk (768 / 12 / 12),
+DINO head with K = 65536 prototypes, 2 global 256^2 crops + 8 local 96^2 crops per image, block-wise iBOT masks from the
+collate (vtp_amd/data.py), B = 2 images, non-zero centres, a teacher that differs from the student -- the HIP path against the
+CPU oracle (oracle/vtp_oracle.py `ssl_outputs` / `ssl_loss`, fp32) for
+
+  * VTP.get_teacher_forward_outputs / get_student_ssl_outputs (vtp/models/vtp.py:410-484) and DINOHead.forward
+    (vtp/models/heads/dino_head.py:65-89): every entry of the two output dicts;
+  * the DINO + iBOT loss value and its gradients through the DINO head, the mask token and the trunk (first / middle / last
+    block), alone (rec weight 0) and inside the FULL benchmarked step (rec + clip + ssl through one list forward of
+    [images | masked global crops | local crops], N = 257 and N = 37 segments).
+
+Protocol = tests/test_parity_bs_gpu.py: E_ours = |ours - ref_fp32| <= 1.25 x E_ref, E_ref = the error of the
+reference algorithm under bf16 autocast, measured live on the CPU and on this MI355X with stock PyTorch-ROCm kernels; no
+absolute floors.  Every comparison prints E_ours, both E_ref and the ratio (the log is committed under profiles/)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HV = HD = HT = 12
+N_LOCAL = 8
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def relF(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(what, ours, ref, cpu16, gpu16, slack=1.25):
+    e, ec, eg = relF(ours, ref), relF(cpu16, ref), relF(gpu16, ref)
+    e_ref = max(ec, eg)
+    print(f"PARITY {what}: E_ours={e:.3e} E_ref(cpu autocast)={ec:.3e} E_ref(cuda autocast)={eg:.3e} "
+          f"E_ours/E_ref={e / max(e_ref, 1e-30):.2f}")
+    assert e <= slack * e_ref, f"{what}: E_ours {e:.3e} > {slack} x E_ref {e_ref:.3e}"
+    return e / max(e_ref, 1e-30)
+
+
+def _captions(B, T, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, vocab - 2, (B, T), generator=g)
+    ids[:, 0] = vocab - 2
+    ln = torch.randint(8, T, (B,), generator=g)
+    ids = torch.where(torch.arange(T)[None, :] < ln[:, None], ids, torch.zeros_like(ids))
+    ids[torch.arange(B), ln] = vocab - 1
+    return ids
+
+
+class Case:
+    """Seeded VTP-B + DINO head (K = 65536) + EMA teacher, one SSL batch, and the oracle's results in fp32 / CPU autocast /
+    CUDA autocast: head outputs, the SSL loss with its gradients, and the full step's loss with its gradients."""
+
+    def __init__(self):
+        from oracle import vtp_oracle as O
+        from vtp_amd import VTP, VTPConfig
+        from vtp_amd.data import collate_ssl_masks
+        self.O = O
+        torch.manual_seed(31)
+        m = VTP(VTPConfig(), dino_out_dim=65536)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.ndim <= 1 and n != "logit_scale" and not n.startswith("teacher_"):
+                    p.add_(0.05 * torch.randn_like(p))
+            # an EMA teacher mid-training: close to the student, not equal to it
+            sd0 = m.state_dict()
+            for n, p in m.named_parameters():
+                if n.startswith("teacher_trunk.") or n.startswith("teacher_dino_head."):
+                    s = sd0[n.replace("teacher_trunk.", "trunk.").replace("teacher_dino_head.", "dino_head.")]
+                    p.copy_(s + (0.002 if p.ndim >= 2 else 0.01) * torch.randn_like(s))
+        self.sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        self.model = m.to(DEV)
+        B = 2
+        g = torch.Generator().manual_seed(7)
+        self.img = torch.randn(B, 3, 256, 256, generator=g)
+        self.txt = _captions(B, 77, 49408, 8)
+        self.gc = torch.randn(2 * B, 3, 256, 256, generator=g)
+        self.lc = torch.randn(N_LOCAL * B, 3, 96, 96, generator=g)
+        col = collate_ssl_masks(2 * B, (16, 16), 0.5, (0.1, 0.5), np.random.default_rng(11))
+        self.col, self.masks = col, col["masks"]
+        K = 65536
+        self.c_d = 0.3 * torch.randn(K, generator=g)
+        self.c_i = 0.3 * torch.randn(K, generator=g)
+        self.out, self.grads_ssl, self.grads_full, self.loss = {}, {}, {}, {}
+        import contextlib
+        for tag, dev, ac in (("f32", "cpu", None), ("cpu16", "cpu", "cpu"), ("gpu16", DEV, "cuda")):
+            ctx = (lambda: torch.autocast(ac, dtype=torch.bfloat16)) if ac else contextlib.nullcontext
+            mv = lambda t: t.to(dev)
+            s2 = {k: v.clone().to(dev).requires_grad_(v.dtype == torch.float32 and not k.startswith("teacher_"))
+                  for k, v in self.sd.items()}
+            with ctx():
+                t_out, s_out = O.ssl_outputs(s2, mv(self.gc), mv(self.lc), mv(self.masks), HV)
+                # the oracle's loss builds its index / weight tensors on the CPU: evaluate it there on (differentiable) fp32 copies
+                l_ssl = O.ssl_loss({k: v.float().cpu() for k, v in t_out.items()}, {k: v.float().cpu() for k, v in s_out.items()},
+                                   self.masks, self.c_d, self.c_i, N_LOCAL)
+            l_ssl.backward()
+            self.out[tag] = ({k: v.detach().float().cpu() for k, v in t_out.items()},
+                             {k: v.detach().float().cpu() for k, v in s_out.items()})
+            self.grads_ssl[tag] = {k: v.grad.detach().float().cpu().clone() for k, v in s2.items() if v.grad is not None}
+            self.loss[tag] = float(l_ssl.detach())
+            del t_out, s_out
+            # the full step = ssl + rec + clip: the second backward ACCUMULATES into the same fp32 .grad tensors, exactly as one
+            # backward of the summed loss would
+            with ctx():
+                l1, lc_ = O.rec_clip_train_loss(s2, mv(self.img), mv(self.txt), HV, HD, HT)
+            (l1 + lc_).backward()
+            self.grads_full[tag] = {k: v.grad.detach().float().cpu() for k, v in s2.items() if v.grad is not None}
+            if tag == "f32":
+                self.loss_full = (float(l1.detach()), float(lc_.detach()), float(l_ssl.detach()))
+            del s2
+
+
+_CASE = []
+
+
+def case() -> Case:
+    if not _CASE:
+        _CASE.append(Case())
+    return _CASE[0]
+
+
+TRUNK_KEYS = [f"trunk.blocks.{i}.{n}" for i in (0, 5, 11)
+              for n in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "mlp.w1.weight", "mlp.w2.bias", "mlp.w3.weight",
+                        "norm1.weight", "norm2.weight")] + \
+             ["trunk.patch_embed.proj.weight", "trunk.patch_embed.proj.bias", "trunk.cls_token", "trunk.mask_token", "trunk.norm.weight"]
+HEAD_KEYS = ["dino_head.mlp.0.weight", "dino_head.mlp.0.bias", "dino_head.mlp.2.weight", "dino_head.mlp.4.weight",
+             "dino_head.mlp.4.bias", "dino_head.last_layer.weight_v", "dino_head.last_layer.weight_g"]
+
+
+def test_ssl_head_outputs_at_benchmarked_config():
+    """teacher / student dicts of VTP.forward(forward_type='ssl') at D = 768, K = 65536, N = 257 + N = 37"""
+    c = case()
+    col = c.col
+    with torch.no_grad():
+        c.model.eval()
+        t_out, s_out = c.model.forward_ssl_learning(c.gc.to(DEV), 2, col["mask_indices_list"].to(DEV), int(col["n_masked_patches"]),
+                                                    col["upperbound"], c.lc.to(DEV), c.masks.to(DEV))
+        c.model.train()
+    ref_t, ref_s = c.out["f32"]
+    for k in ("teacher_cls_tokens_after_head", "masked_teacher_patch_tokens_after_head"):
+        check(f"SSL teacher {k}", t_out[k], ref_t[k], c.out["cpu16"][0][k], c.out["gpu16"][0][k])
+    for k in ("student_local_cls_tokens_after_head", "student_global_cls_tokens_after_head", "student_global_cls_tokens",
+              "student_global_masked_patch_tokens_after_head"):
+        check(f"SSL student {k}", s_out[k], ref_s[k], c.out["cpu16"][1][k], c.out["gpu16"][1][k])
+    assert int(t_out["n_masked_patches"]) == int(c.masks.sum())
+
+
+def _compare_grads(tag, params, keys, G):
+    worst, worst_k = 0.0, None
+    for k in keys:
+        r = check(f"{tag} grad {k}", params[k].grad, G["f32"][k], G["cpu16"][k], G["gpu16"][k])
+        if r > worst:
+            worst, worst_k = r, k
+    num = den = ref_c = ref_g = 0.0
+    n = 0
+    for k, g in G["f32"].items():
+        if k not in params or params[k].grad is None:
+            continue
+        o = params[k].grad.float().cpu()
+        num += float((o - g).pow(2).sum())
+        den += float(g.pow(2).sum())
+        ref_c += float((G["cpu16"][k] - g).pow(2).sum())
+        ref_g += float((G["gpu16"][k] - g).pow(2).sum())
+        n += 1
+    e, e_ref = (num / den) ** 0.5, (max(ref_c, ref_g) / den) ** 0.5
+    print(f"PARITY {tag} ALL {n} gradient tensors (flat): E_ours={e:.3e} E_ref={e_ref:.3e} E_ours/E_ref={e / e_ref:.2f}; "
+          f"worst sampled key {worst_k}: {worst:.2f}")
+    assert e <= 1.25 * e_ref
+
+
+def _trainer(c, **kw):
+    from vtp_amd import VTPTrainer
+    tr = VTPTrainer(c.model, lr=0.0, weight_decay=0.0, teacher_momentum=1.0, **kw)  # lr 0, momentum 1: the step leaves the weights alone
+    tr.center_dino.copy_(c.c_d)
+    tr.center_ibot.copy_(c.c_i)
+    ssl = tr.prepare_ssl(c.gc.to(DEV), c.lc.to(DEV), c.masks, upperbound=c.col["upperbound"])
+    return tr, ssl
+
+
+def test_ssl_loss_and_gradients_at_benchmarked_config():
+    """DINO + iBOT alone (rec weight 0): loss, dino_head.*, mask_token, trunk gradients vs the oracle's autograd"""
+    c = case()
+    tr, ssl = _trainer(c, rec_weight=0.0)
+    tr.step(c.img.to(DEV), None, ssl)
+    torch.cuda.synchronize()
+    loss = float(tr.ssl_loss_sum)
+    e, e_ref = abs(loss - c.loss["f32"]), max(abs(c.loss["cpu16"] - c.loss["f32"]), abs(c.loss["gpu16"] - c.loss["f32"]))
+    print(f"PARITY SSL loss: ours={loss:.6f} oracle fp32={c.loss['f32']:.6f} cpu16={c.loss['cpu16']:.6f} gpu16={c.loss['gpu16']:.6f} "
+          f"|err| ours={e:.2e} ref={e_ref:.2e}")
+    assert e <= max(1.25 * e_ref, 2e-4 * abs(c.loss["f32"]))  # a scalar: floor at 2e-4 relative (one bf16 logit ulp over 65536 terms)
+    _compare_grads("SSL-only", dict(c.model.named_parameters()), HEAD_KEYS + TRUNK_KEYS, c.grads_ssl)
+
+
+def test_full_step_gradients_at_benchmarked_config():
+    """the step bench.py times (rec + clip + DINO/iBOT, one list forward, one trunk backward) at B = 2 vs the oracle's autograd of
+    l1 + clip + ssl"""
+    c = case()
+    tr, ssl = _trainer(c)
+    l1, lc = tr.step(c.img.to(DEV), c.txt.to(DEV), ssl)
+    torch.cuda.synchronize()
+    print(f"PARITY full step losses: ours L1={float(l1):.6f} clip={float(lc):.6f} ssl={float(tr.ssl_loss_sum):.6f} | oracle fp32 "
+          f"L1={c.loss_full[0]:.6f} clip={c.loss_full[1]:.6f} ssl={c.loss_full[2]:.6f}")
+    assert abs(float(l1) - c.loss_full[0]) < 2e-3 * c.loss_full[0]
+    assert abs(float(lc) - c.loss_full[1]) < 5e-3 * max(c.loss_full[1], 1e-3)
+    assert abs(float(tr.ssl_loss_sum) - c.loss_full[2]) < 1e-3 * c.loss_full[2]
+    dec = [f"pixel_decoder.blocks.{i}.{n}" for i in (0, 11) for n in ("attn.qkv.weight", "mlp.w3.weight", "norm2.weight")]
+    txt = [f"text_transformer.resblocks.{i}.{n}" for i in (0, 11) for n in ("attn.in_proj_weight", "mlp.c_fc.weight")]
+    _compare_grads("FULL step", dict(c.model.named_parameters()),
+                   HEAD_KEYS + TRUNK_KEYS + dec + txt + ["trunk.feature_bottleneck.weight", "visual_proj.weight", "logit_scale"],
+                   c.grads_full)

@@ -115,6 +115,30 @@ def test_ssl_kernels_vs_torch():
     assert abs(float(loss) - float(tot)) < 1e-4 * abs(float(tot))
     assert relF(dS, sr.grad) < 6e-3, relF(dS, sr.grad)
     assert float(dS[6].float().abs().max()) == 0.0 and float(dS[7].float().abs().max()) == 0.0  # padding rows
+    # the benchmarked prototype count (K = 65536, the register-resident row kernels), student rows with two / one / no target
+    Kb, Ttb, Tsb = 65536, 5, 7
+    tlb = bf(torch.randn(Ttb, Kb, device=DEV, generator=g) * 2)
+    pb = torch.empty(Ttb, Kb, dtype=torch.bfloat16, device=DEV)
+    o.softmax_center(tlb, torch.randn(Kb, device=DEV, generator=g) * 0.1, 1 / 0.07, pb, Ttb, Kb)
+    slb = bf(torch.randn(Tsb, Kb, device=DEV, generator=g) * 2)
+    t0b = torch.tensor([0, 1, 2, 3, 4, -1, 2], dtype=torch.int32, device=DEV)
+    t1b = torch.tensor([1, -1, 4, -1, 0, -1, -1], dtype=torch.int32, device=DEV)
+    wb = torch.tensor([0.5, 0.25, 1.0, 0.125, 0.3, 0.9, 0.2], device=DEV)
+    lossb = torch.zeros(1, device=DEV)
+    dSb = torch.full((Tsb, Kb), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.dino_ce(slb, pb, t0b, t1b, wb, 10.0, lossb, dSb, Tsb, Kb)
+    srb = slb.float().requires_grad_(True)
+    lsmb = F.log_softmax(srb * 10.0, dim=-1)
+    totb = 0.0
+    for r in range(Tsb):
+        if t0b[r] < 0:
+            continue
+        q = pb[t0b[r]].float() + (pb[t1b[r]].float() if t1b[r] >= 0 else 0.0)
+        totb = totb - wb[r] * (q * lsmb[r]).sum()
+    totb.backward()
+    assert abs(float(lossb) - float(totb)) < 1e-4 * abs(float(totb)), (float(lossb), float(totb))
+    assert relF(dSb, srb.grad) < 6e-3, relF(dSb, srb.grad)
+    assert float(dSb[5].float().abs().max()) == 0.0
     # centre EMA with a device-side count; mask-row backward
     c = torch.randn(Kp, device=DEV, generator=g)
     cs = torch.randn(Kp, device=DEV, generator=g)

@@ -24,7 +24,8 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in _sources() + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "vtp_hip.h")]:
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for f in _sources() + hdrs + [os.path.join(ROOT, "include", "vtp_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -341,9 +341,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   seg_barrier();
 
   int ktg = 0;  // k-tiles computed so far (across my tiles): ring half = ktg & 1
+  auto stamp = [&](int ti, int which) {
+    if (__builtin_expect(p.timing != nullptr, 0) && tid == 0 && ti < 16)
+      p.timing[((size_t)blockIdx.x * 16 + ti) * 4 + which] = wall_clock64();
+  };
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
     tile_origin(ti, m0, n0);
+    stamp(ti, 0);
     if constexpr (TRANS) do_csum = p.colsum != nullptr && wc == 0 && n0 == 0;
     if (STAGGER && wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       seg_barrier();
     }
     if (STAGGER && wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
+    stamp(ti, 1);
     if constexpr (TRANS) {
       if (do_csum) {
 #pragma unroll
@@ -403,12 +409,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
     gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
+    stamp(ti, 2);
     zero_acc();
   }
 }
 
+// diagnostics (vtp_gemm_debug): stamp buffer and a cap on the persistent grid (0 = every CU)
+static unsigned long long* g_p8_timing = nullptr;
+static int g_p8_grid = 0;
+
 template <int EPI, bool TRANS, int VAR = 0>
-static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
+static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
+  GemmArgs a = a0;
+  a.timing = g_p8_timing;
   auto kern = gemm8p_kernel<EPI, TRANS, VAR>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -432,7 +445,8 @@ static int launch8p(const GemmArgs& a, int splits, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(512), P8_LDS, s, f);
     return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
   }
-  dim3 grid(splits == 1 && ntiles > cus ? cus : ntiles, 1, splits);
+  const int cap = g_p8_grid > 0 ? g_p8_grid : cus;
+  dim3 grid(splits == 1 && ntiles > cap ? cap : ntiles, 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS, s, a);
   return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
 }
@@ -487,3 +501,11 @@ int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 }
 
 }  // namespace vtp
+
+// diagnostics for tools/gemm8p_timeline.py: `timing` = device buffer of [workgroups][16 tiles][4] u64 s_memrealtime stamps (100 MHz)
+// written by the 8-phase kernel (null: off); grid_limit caps its persistent grid (0: every CU)
+extern "C" int vtp_gemm_debug(void* timing, int grid_limit) {
+  vtp::g_p8_timing = (unsigned long long*)timing;
+  vtp::g_p8_grid = grid_limit;
+  return VTP_OK;
+}

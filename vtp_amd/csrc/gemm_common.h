@@ -44,6 +44,8 @@ struct GemmArgs {
   // null: plain epilogue.
   const bf16* swiglu_pre;
   int swiglu_ld;
+  // diagnostics (vtp_gemm_debug): per workgroup and tile, s_memrealtime stamps {tile start, k loop done, epilogue issued}; null = off
+  unsigned long long* timing;
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,

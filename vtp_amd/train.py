@@ -37,18 +37,22 @@ class GradBucketer:
 
     Pure torch.distributed (works with gloo on CPU for tests, nccl==RCCL on MI355X)."""
 
-    def __init__(self, flat_g: torch.Tensor, group=None, shard: bool = False, grad_dtype: torch.dtype = torch.float32):
+    def __init__(self, flat_g: torch.Tensor, group=None, shard: bool = False, grad_dtype: torch.dtype = torch.float32,
+                 force: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.flat_g = flat_g
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # `force`: issue every collective even in a one-rank group (they are identities there) -- puts the RCCL code path on
+        # hardware on a one-GPU box (tests/test_rccl_gpu.py)
+        self.active = self.world > 1 or (bool(force) and dist.is_available() and dist.is_initialized())
         self.works = []
         self.reduced_elems = 0
         # sharded mode (reduce-scatter + rank-sharded AdamW + parameter all-gather): every bucket [lo, hi) is cut into
         # `world` equal chunks (8-element aligned, the last one zero-padded); rank r owns chunk r of every bucket
-        self.shard = bool(shard) and self.world > 1
+        self.shard = bool(shard) and self.active
         self.grad_dtype = grad_dtype
         self.shards: dict = {}      # (lo, hi) -> ShardRec
         self.comm_bytes = 0
@@ -96,7 +100,7 @@ class GradBucketer:
 
     def reduce_range(self, lo: int, hi: int):
         """Launch (async) sum-all-reduce of flat_g[lo:hi]."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if self.shard:
             return self.reduce_scatter_range(lo, hi)
@@ -168,7 +172,8 @@ class VTPTrainer:
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
                  lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
                  drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3,
-                 shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32", no_decay="default"):
+                 shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32", no_decay="default",
+                 force_collectives: bool = False):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
@@ -239,8 +244,10 @@ class VTPTrainer:
             raise ValueError(f"grad_dtype must be 'fp32' or 'bf16', got {grad_dtype!r}")
         if grad_dtype == "bf16" and not shard_optimizer:
             raise ValueError("grad_dtype='bf16' needs shard_optimizer=True (the all-reduce path reduces the flat fp32 buffer in place)")
-        self.bucketer = GradBucketer(st.flat_g, group, shard=shard_optimizer, grad_dtype=BF if grad_dtype == "bf16" else F32)
+        self.bucketer = GradBucketer(st.flat_g, group, shard=shard_optimizer, grad_dtype=BF if grad_dtype == "bf16" else F32,
+                                     force=force_collectives)
         self.shard_optimizer = self.bucketer.shard
+        self.collectives = self.bucketer.active  # world > 1, or a one-rank group with force_collectives
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
         self._comm_events = []
         self.world, self.rank, self.group = self.bucketer.world, self.bucketer.rank, group
@@ -263,7 +270,7 @@ class VTPTrainer:
     def sync_replicas(self):
         """Data-parallel replicas must start from identical state (what DDP's constructor does with its parameter / buffer
         broadcast): rank 0's fp32 masters (student AND EMA teacher), Adam moments and SSL centres go to every rank."""
-        if self.world == 1:
+        if not self.collectives:
             return
         dist, st = self.bucketer.dist, self.store
         bufs = [st.flat_p, self.m, self.v]
@@ -297,7 +304,7 @@ class VTPTrainer:
         return plan
 
     def _reduce(self, keys: Sequence[str]):
-        if self.world == 1 or not keys:
+        if not self.collectives or not keys:
             return
         rs = merge_ranges([r for k in keys for r in self._bucket_plan[k]])
         for lo, hi in rs:
@@ -351,7 +358,7 @@ class VTPTrainer:
             # masked-patch rows: the first n_masked of the Tm padded rows, n_masked read from device memory (graph-replay safe)
             ops.colsum_bf16_rows(t_logits[B2:], K, stats[K:], P["dev"]["n_masked_i"], Tm, K)
             stats[2 * K:2 * K + 1].copy_(P["dev"]["n_masked_f"])
-            if self.world > 1:
+            if self.collectives:
                 yield lambda: dist.all_reduce(stats, group=self.group)
             ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
             ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
@@ -382,7 +389,7 @@ class VTPTrainer:
                                                           P["dev"]["n_masked_i"], 0.0)):
             u, v = ws.get(f"sk.u.{tag}", (T,), F32), ws.get(f"sk.v.{tag}", (K,), F32)
             scr = ws.get(f"sk.s.{tag}", (8 + K + T,), F32)
-            if self.world == 1:
+            if not self.collectives:
                 ops.sinkhorn_knopp(lg, inv_t, pr, u, v, scr, T, K, count, it, -1, cnt_dev, rows_dev)
                 continue
             if cnt_dev is not None:  # global masked-token count
@@ -494,7 +501,7 @@ class VTPTrainer:
                 f_txt = self.text.forward(text, train=True)
             txt_n, inv_t = self.clip.normalize(f_txt, "txt")
             Bg = B * self.world
-            if self.world > 1:
+            if self.collectives:
                 img_all = cw.get("img_all", (Bg, Dt), F32)
                 txt_all = cw.get("txt_all", (Bg, Dt), F32)
 
@@ -519,7 +526,7 @@ class VTPTrainer:
             else:
                 ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
                               d_img_l, d_txt_l, d_img_all, d_txt_all, st.g("logit_scale"), scratch)
-            if self.world > 1:
+            if self.collectives:
                 rs_i = cw.get("rs_i", (B, Dt), F32)
                 rs_t = cw.get("rs_t", (B, Dt), F32)
 
