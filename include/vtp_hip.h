@@ -60,13 +60,21 @@ int vtp_gemm_tn_splits(int M, int N, int K);
 int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int ldc2, const float* resid, int M, int N,
                 int K, int epilogue, int a_grp, int a_pre, int b_grp, int b_pre, int c_grp, int c_pre, int splits,
                 float* a_colsum, void* stream);
+/* The weight gradients of one transformer block as ONE launch: up to 8 problems C_g[M_g, N_g] (+)= A_g[K, M_g]^T B_g[K, N_g] that
+ * reduce over the same K token rows (nn.Linear backward dW = dY^T X of attn.qkv / attn.proj / mlp.w1|w2 / mlp.w3, block.py:290-296),
+ * (sum of 256 x 256 tiles) x splits workgroups; the K slices of a tile are combined inside the launch by the last-arriving
+ * workgroup, which applies the epilogue (accumulate or overwrite, SwiGLU row de-interleave c_grp = -1, bias-gradient column sums).
+ * probs: device array of nprob records of 16 int64 {A, B, C, colsum | lda, ldb, ldc | M, N | c_grp, c_pre | tile0 | accumulate | 0 0 0};
+ * part: ntiles * splits_eff * 65536 floats, ticket: ntiles ints, zero before the first launch (the kernel leaves them zero). */
+int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, void* stream);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
 /* diagnostics (tools/gemm8p_timeline.py): `timing` = device buffer of [workgroups][16 tiles][4] 64-bit s_memrealtime stamps
  * {tile start, k loop done, epilogue issued} written by the 256x256 kernel (null = off); grid_limit caps its persistent grid
- * (0 = every CU).  Process-global; not part of the reference-facing surface. */
-int vtp_gemm_debug(void* timing, int grid_limit);
+ * (0 = every CU); delay_ticks > 0 starts every second workgroup of an XCD that many 10-ns ticks late (lock-step experiments).
+ * Process-global; not part of the reference-facing surface. */
+int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks);
 int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);

@@ -117,7 +117,7 @@ def test_stochastic_depth_step_vs_oracle(init_values):
     torch.cuda.synchronize()
 
     def plan_of(stack):
-        p = stack.drop_plan
+        p = stack.last_drop_plan  # the trainer clears the active plan when the step ends
         keep, alpha = p["keeps"][0], p["scales"][0]
         assert keep == 3 and abs(alpha - B / 3) < 1e-9
         idx = p["idx_dev"].cpu().long().view(stack.depth, 2, keep)
@@ -144,9 +144,13 @@ def test_stochastic_depth_step_vs_oracle(init_values):
         keys += ["trunk.blocks.1.ls1.gamma", "pixel_decoder.blocks.0.ls2.gamma"]
     _compare_grads(m, ref, keys, 3e-2, ref16)
     # a second step draws new subsets (same shapes: static index buffer refreshed in place) and the graph path agrees with eager
-    i0 = tr.trunk.stack.drop_plan["idx_dev"].clone()
+    i0 = tr.trunk.stack.last_drop_plan["idx_dev"].clone()
     tr.step_rec(img.to(DEV))
-    assert not torch.equal(i0, tr.trunk.stack.drop_plan["idx_dev"])
+    assert not torch.equal(i0, tr.trunk.stack.last_drop_plan["idx_dev"])
+    # the plan does not outlive the step: an evaluation pass with another batch size afterwards runs the plain path
+    assert tr.trunk.stack.drop_plan is None and tr.decoder.stack.drop_plan is None
+    feats = m.get_intermediate_layers_feature(img[:2].to(DEV), n=1)
+    assert torch.isfinite(feats[0]).all()
     res = []
     for use_graphs in (False, True):
         m2, _ = _model(init_values)

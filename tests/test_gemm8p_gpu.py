@@ -174,3 +174,58 @@ def test_gemm8p_tn_fused_bias_gradient(Mo, No, K, splits, swiglu):
         ref_c, ref_b = rc, rb
     check(C, ref_c, f"gemm8p_tn + colsum C {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)
     check(db, 1 + ref_b, f"gemm8p_tn fused bias gradient {Mo}x{No}x{K}", bf16_out=False, scale=2e-5)
+
+
+@pytest.mark.parametrize("Ktok,D,H", [(2134, 768, 2048), (514, 384, 1024), (34144, 768, 2048), (1100, 128, 344)])
+def test_grouped_wgrad_matches_torch(Ktok, D, H):
+    """ops.WgradGroup (vtp_gemm_tn_grouped): the four weight gradients of a block in ONE launch -- in-launch split-K combine by the
+    last arriver (1, 2 or more slices), SwiGLU row de-interleave, fused bias-gradient column sums, C += and C = modes, and a second
+    launch on the same scratch (tickets must be back at zero)."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(Ktok + D)
+    dqkv = bf(torch.randn(Ktok, 3 * D, device=DEV, generator=g))
+    dmid = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    dpre = bf(torch.randn(Ktok, 2 * H, device=DEV, generator=g))     # interleaved 8 | 8 (w1 | w2) columns
+    dy = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    xn1 = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    att = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    xn2 = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    hid = bf(torch.randn(Ktok, H, device=DEV, generator=g))
+    probs = [(dy, hid, D, H, 0, False), (dpre, xn2, 2 * H, D, H, True), (dmid, att, D, D, 0, False), (dqkv, xn1, 3 * D, D, 0, True)]
+    gws = [torch.randn(N * K, device=DEV, generator=g) for _, _, N, K, _, _ in probs]
+    gbs = [torch.randn(N, device=DEV, generator=g) if cs else None for _, _, N, _, _, cs in probs]
+    gw0 = [t.clone() for t in gws]
+    gb0 = [None if t is None else t.clone() for t in gbs]
+    grp = o.WgradGroup(Ktok)
+    for (a, x, N, K, sh, _), gw, gb in zip(probs, gws, gbs):
+        grp.add(a, x, gw, gb, N, K, sh)
+    scratch = {}
+    grp.finalize(DEV, scratch)
+    print(f"grouped wgrad Ktok={Ktok}: {grp.ntiles} tiles x {grp.splits} slices")
+    grp.launch()
+    grp.launch()  # accumulates twice
+    torch.cuda.synchronize()
+    if grp.splits > 1:
+        assert int(scratch["ticket"].abs().sum()) == 0, "tickets must return to zero"
+    for (a, x, N, K, sh, cs), gw, gb, w0, b0 in zip(probs, gws, gbs, gw0, gb0):
+        ref = a.float().T @ x.float()                                    # [N, K]
+        col = a.float().sum(0)
+        if sh:  # de-interleave the GEMM's rows: 16-row groups = 8 rows of w1 | 8 rows of w2
+            idx = torch.arange(N, device=DEV)
+            dst = ((idx >> 4) << 3) + (idx & 7) + torch.where((idx & 8) != 0, sh, 0)
+            r2, c2 = torch.empty_like(ref), torch.empty_like(col)
+            r2[dst], c2[dst] = ref, col
+            ref, col = r2, c2
+        check(gw.view(N, K), w0.view(N, K) + 2 * ref, f"grouped dW N={N} K={K}", bf16_out=False, scale=1e-4)
+        if cs:
+            check(gb, b0 + 2 * col, f"grouped db N={N}", bf16_out=False, scale=1e-4)
+    # overwrite mode + a group with a forced 3-way split through the C ABI's splits argument
+    out = torch.full((D * H,), float("nan"), device=DEV)
+    g1 = o.WgradGroup(Ktok)
+    g1.add(dy, hid, out, None, D, H, 0, accumulate=False)
+    g1.finalize(DEV, {})
+    g1.splits = 3  # the launcher rounds the slices to whole k-tiles (the effective count may come out lower)
+    g1.part = torch.empty(g1.ntiles * 3 * 65536, device=DEV)
+    g1.ticket = torch.zeros(max(g1.ntiles, 256), dtype=torch.int32, device=DEV)
+    g1.launch()
+    check(out.view(D, H), dy.float().T @ hid.float(), "grouped dW overwrite", bf16_out=False, scale=1e-4)

@@ -33,9 +33,12 @@ def relF(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def check(what, ours, ref, cpu16, gpu16, slack=1.25):
+def check(what, ours, ref, cpu16, gpu16, slack=1.25, e_ref_min=0.0):
+    """e_ref_min: for a SCALAR gradient (logit_scale) the relative error of one bf16 execution is a single random draw (0.2 % .. 5 %
+    in the committed logs), not an aggregate -- its reference noise is taken no lower than that of the tensor whose entries
+    it sums (visual_proj.weight: the same (p - y) . cos terms)."""
     e, ec, eg = relF(ours, ref), relF(cpu16, ref), relF(gpu16, ref)
-    e_ref = max(ec, eg)
+    e_ref = max(ec, eg, e_ref_min)
     print(f"PARITY {what}: E_ours={e:.3e} E_ref(cpu autocast)={ec:.3e} E_ref(cuda autocast)={eg:.3e} "
           f"E_ours/E_ref={e / max(e_ref, 1e-30):.2f}")
     assert e <= slack * e_ref, f"{what}: E_ours {e:.3e} > {slack} x E_ref {e_ref:.3e}"
@@ -152,8 +155,11 @@ def test_ssl_head_outputs_at_benchmarked_config():
 
 def _compare_grads(tag, params, keys, G):
     worst, worst_k = 0.0, None
+    vp = "visual_proj.weight"
+    floor = max(relF(G["cpu16"][vp], G["f32"][vp]), relF(G["gpu16"][vp], G["f32"][vp])) if vp in G["f32"] else 0.0
     for k in keys:
-        r = check(f"{tag} grad {k}", params[k].grad, G["f32"][k], G["cpu16"][k], G["gpu16"][k])
+        r = check(f"{tag} grad {k}", params[k].grad, G["f32"][k], G["cpu16"][k], G["gpu16"][k],
+                  e_ref_min=floor if G["f32"][k].numel() == 1 else 0.0)
         if r > worst:
             worst, worst_k = r, k
     num = den = ref_c = ref_g = 0.0

@@ -37,13 +37,13 @@ def run(lib, tag, M, N, K, epi, grid, g):
     lib.vtp_set_gemm_tuning(8, 3)
     for _ in range(3):
         ops.gemm_nt(a, b, c, M=M, N=N, K=K, epi=epi, **kw)
-    lib.vtp_gemm_debug(tbuf.data_ptr(), grid)
+    lib.vtp_gemm_debug(tbuf.data_ptr(), grid, 0)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     ops.gemm_nt(a, b, c, M=M, N=N, K=K, epi=epi, **kw)
     e1.record()
     torch.cuda.synchronize()
-    lib.vtp_gemm_debug(None, 0)
+    lib.vtp_gemm_debug(None, 0, 0)
     us = e0.elapsed_time(e1) * 1e3
     t = tbuf.view(nwg, 16, 4).cpu().double() / 100.0  # us
     G = grid if grid else 256
@@ -69,9 +69,43 @@ def run(lib, tag, M, N, K, epi, grid, g):
     sys.stdout.flush()
 
 
+def delay_sweep(lib, tag, M, N, K, epi, g):
+    """launch time with every second workgroup started late: if the epilogue store bursts of a lock-stepped chip are what costs,
+    a half-tile offset between the two halves wins more than the idle start loses"""
+    dev = "cuda"
+    a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    b = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    if epi == ops.EPI_BF16:
+        c, kw = torch.empty(M, N, dtype=torch.bfloat16, device=dev), dict(bias=bias)
+    elif epi == ops.EPI_F32:
+        c = torch.zeros(M, N, device=dev)
+        kw = dict(bias=bias, resid=c)
+    else:
+        c = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
+        kw = dict(bias=bias, c2=torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+    lib.vtp_set_gemm_tuning(8, 3)
+    delays = [0, 400, 800, 1200, 1700, 2400]
+    res = {d: [] for d in delays}
+    for _ in range(5):
+        for d in delays:
+            lib.vtp_gemm_debug(None, 0, d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.gemm_nt(a, b, c, M=M, N=N, K=K, epi=epi, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            res[d].append(e0.elapsed_time(e1) * 200.0)
+    lib.vtp_gemm_debug(None, 0, 0)
+    print(f"== delay sweep {tag} M={M} N={N} K={K}: " + "  ".join(f"{d / 100:.0f}us:{sorted(v)[2]:.1f}" for d, v in res.items()), flush=True)
+
+
 def main():
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(0)
+    for tag, M, N, K, epi in SHAPES:
+        delay_sweep(lib, tag, M, N, K, epi, g)
     for tag, M, N, K, epi in SHAPES:
         for grid in (0, 32):
             Mg = M if grid == 0 else (M // 8 // 256) * 256  # an eighth of the rows on an eighth of the chip

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vtp_gemm_tn_splits": [_I, _I, _I],
     "vtp_gemm_qkv_rope": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "vtp_gemm_tn_grouped": [_P, _I, _I, _I, _I, _P, _P, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_colsum_bf16_rows": [_P, _I, _P, _P, _I, _I, _P],
     "vtp_gather_image_rows": [_P, _P, _P, _P, _I, _L, _I, _F, _P],
@@ -48,7 +49,7 @@ SIGNATURES = {
     "vtp_qk_norm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "vtp_qk_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
-    "vtp_gemm_debug": [_P, _I],
+    "vtp_gemm_debug": [_P, _I, _I],
     "vtp_norm_fwd_e4m3": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "vtp_quantize_e4m3": [_P, _I, _P, _L, _P, _F, _P],
     "vtp_amax": [_P, _I, _L, _P, _P],

@@ -69,8 +69,15 @@ struct P8Frags<true> {
   p8_i32x8 g[2];
 };
 
+// one (tile, K slice) of a grouped weight-gradient launch: the split-K combine of its tile happens in the launch (see GroupArgs)
+struct GroupTile {
+  float* part;   // fp32 partial sums, fragment-major [tiles][splits][8 waves][32][64 lanes] float4; null: no combine (one slice)
+  int* ticket;   // one arrival counter per tile (zero between launches: the last arriver resets it)
+  int tile, splits;
+};
+
 template <int EPI, bool TRANS, int VAR = 0>
-__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslice, const int G, const bool flat, const GroupTile gt) {
   constexpr bool STAGGER = !(VAR & 1), SETPRIO = !(VAR & 2), DMA_IN_MMA = (VAR & 4) != 0;
   // VAR bit 3: the operands are fp8 (e4m3, OCP) -- same bytes, same staging, same fragment reads (the launcher passes K and the
   // leading dimensions in 2-byte units); only the MFMA changes: v_mfma_f32_32x32x64_f8f6f4 takes 32 B per lane, i.e. two of
@@ -86,18 +93,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   const int tiles_m = (p.M + 255) >> 8;
   const int tiles_n = (p.N + 255) >> 8;
   const int ntiles = tiles_m * tiles_n;
-  // split-K launches arrive as ONE flat grid of ntiles x splits workgroups (bit 2 of xcd_swizzle): workgroups are dealt to the 8
-  // XCDs round-robin, and XCD x takes a contiguous chunk of the (split-major) list -- so the tiles that stream the same K slice of
-  // A / B sit behind ONE L2 and that slice is fetched from HBM once, not once per XCD
-  const bool flat = (p.xcd_swizzle & 4) != 0;
-  int bx = blockIdx.x, zslice = blockIdx.z;
-  if (flat) {
-    const int W = gridDim.x, q = W >> 3, r = W & 7, x = bx & 7;
-    const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bx >> 3);
-    zslice = c / ntiles;
-    bx = c - zslice * ntiles;
-  }
-  const int G = flat ? ntiles : gridDim.x;
+  // (bx, zslice, G): this workgroup computes tiles bx, bx + G, ... of K slice zslice (the kernels below derive them from the grid)
   const int n_my = (ntiles - bx + G - 1) / G;
   auto tile_origin = [&](int i, int& m0, int& n0) {
     int wg = bx + i * G;
@@ -324,6 +320,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  if (__builtin_expect(p.dbg_delay > 0, 0) && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)p.dbg_delay) __builtin_amdgcn_s_sleep(16);
+  }
   // ---------------------------------------------------------------- prologue: 7 half-tiles in flight, the first 4 landed
   {
     int m0s, n0s;
@@ -407,6 +407,63 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
         }
       }
     }
+    if constexpr (EPI == EPI_F32 && TRANS) {
+      if (gt.part != nullptr) {
+        // split-K combine inside the launch (cdna_hip_programming.md, "In-launch split-K reduction"): every slice publishes its
+        // accumulators (plain 16-B stores, fragment-major: a lane re-reads exactly its own positions) -> every wave drains its
+        // stores -> barrier -> lane 0: agent-scope release, drain, ticket.  The slice that draws the last ticket acquires, adds the
+        // other slices' partials to its registers in slice order and runs the epilogue; nobody ever waits for another workgroup.
+        f32x4* mine = (f32x4*)gt.part + (((size_t)gt.tile * gt.splits + zslice) * 8 + wave) * 2048 + lane;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+              mine[((i * 4 + j) * 4 + q) * 64] = v;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = (int*)(smem + P8_RING);  // the epilogue staging area is idle here (TN epilogues store directly)
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const int t = __hip_atomic_fetch_add(gt.ticket + gt.tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int last = t == gt.splits - 1;
+          if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(gt.ticket + gt.tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+          }
+          *flag = last;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads();  // the flag word is part of the ring's tail region: nobody rewrites it before everyone has read it
+        if (!last) {
+          stamp(ti, 2);
+          zero_acc();
+          continue;
+        }
+        for (int z = 0; z < gt.splits; ++z) {
+          if (z == zslice) continue;
+          const f32x4* other = (const f32x4*)gt.part + (((size_t)gt.tile * gt.splits + z) * 8 + wave) * 2048 + lane;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {  // 16 loads (64 registers) in flight per lane; the fragment registers are dead here
+            f32x4 v[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = other[(i * 16 + t) * 64];
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][t >> 2][4 * (t & 3) + e] += v[t][e];
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+    }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
     gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
     stamp(ti, 2);
@@ -414,14 +471,75 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   }
 }
 
+template <int EPI, bool TRANS, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+  // split-K launches arrive as ONE flat grid of ntiles x splits workgroups (bit 2 of xcd_swizzle): workgroups are dealt to the 8
+  // XCDs round-robin, and XCD x takes a contiguous chunk of the (split-major) list -- so the tiles that stream the same K slice of
+  // A / B sit behind ONE L2 and that slice is fetched from HBM once, not once per XCD
+  const int ntiles = ((p.M + 255) >> 8) * ((p.N + 255) >> 8);
+  const bool flat = (p.xcd_swizzle & 4) != 0;
+  int bx = blockIdx.x, zslice = blockIdx.z;
+  if (flat) {
+    const int W = gridDim.x, q = W >> 3, r = W & 7, x = bx & 7;
+    const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bx >> 3);
+    zslice = c / ntiles;
+    bx = c - zslice * ntiles;
+  }
+  gemm8p_body<EPI, TRANS, VAR>(p, bx, zslice, flat ? ntiles : (int)gridDim.x, flat, GroupTile{nullptr, nullptr, 0, 1});
+}
+
+// Grouped weight gradients: up to 8 problems C_g[M_g, N_g] (+)= A_g[K, M_g]^T B_g[K, N_g] over the SAME K token rows (the four linear
+// maps of a transformer block) as ONE launch of (sum of their 256 x 256 tiles) x splits workgroups -- one (tile, K slice) each,
+// split-major over the XCDs like the flat split-K launches.  The slices of a tile are combined in the launch by the last arriver
+// (gemm8p_body), which also applies the epilogue (C = C + sum or C = sum, SwiGLU row de-interleave, fused bias-gradient column sums):
+// no slab buffers, no reduce launches, no separate column-sum launches.
+struct GroupProblem {  // 64-bit fields: written by the host as an int64 tensor
+  const bf16* A;
+  const bf16* B;
+  float* C;
+  float* colsum;
+  long lda, ldb, ldc;
+  long M, N;
+  long c_grp, c_pre;
+  long tile0;       // first tile of this problem in the launch's tile list
+  long accumulate;  // 1: C += result, 0: C = result
+  long pad[3];
+};
+struct GroupArgs {
+  const GroupProblem* probs;
+  float* part;
+  int* ticket;
+  int nprob, ntiles, splits, K, k_split;
+  unsigned long long* timing;
+};
+
+__global__ __launch_bounds__(512) void gemm8p_grouped_tn_kernel(const GroupArgs ga) {
+  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
+  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+  const int zslice = c / ga.ntiles, tile = c - zslice * ga.ntiles;
+  int g = 0;
+  for (int i = 1; i < ga.nprob; ++i)
+    if ((int)ga.probs[i].tile0 <= tile) g = i;
+  const GroupProblem& pr = ga.probs[g];
+  GemmArgs p{};
+  p.A = pr.A; p.B = pr.B; p.C = pr.C; p.resid = pr.accumulate ? pr.C : nullptr; p.colsum = pr.colsum;
+  p.M = (int)pr.M; p.N = (int)pr.N; p.K = ga.K; p.lda = (int)pr.lda; p.ldb = (int)pr.ldb; p.ldc = (int)pr.ldc;
+  p.c_grp = (int)pr.c_grp; p.c_pre = (int)pr.c_pre; p.k_split = ga.k_split; p.alpha = 1.f; p.xcd_swizzle = 0;
+  p.timing = ga.timing;
+  const int nt = ((p.M + 255) >> 8) * ((p.N + 255) >> 8);
+  gemm8p_body<EPI_F32, true, 0>(p, tile - (int)pr.tile0, zslice, nt, true,
+                                GroupTile{ga.splits > 1 ? ga.part : nullptr, ga.ticket, tile, ga.splits});
+}
+
 // diagnostics (vtp_gemm_debug): stamp buffer and a cap on the persistent grid (0 = every CU)
 static unsigned long long* g_p8_timing = nullptr;
-static int g_p8_grid = 0;
+static int g_p8_grid = 0, g_p8_delay = 0;
 
 template <int EPI, bool TRANS, int VAR = 0>
 static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
   GemmArgs a = a0;
   a.timing = g_p8_timing;
+  a.dbg_delay = g_p8_delay;
   auto kern = gemm8p_kernel<EPI, TRANS, VAR>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -502,10 +620,36 @@ int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 
 }  // namespace vtp
 
+// One launch for the weight gradients of a transformer block (see gemm8p_grouped_tn_kernel).  probs: device array of `nprob`
+// GroupProblem records (16 x int64 each); ntiles = sum of their 256 x 256 tile counts; part / ticket: device scratch of
+// ntiles * splits * 256 KiB and ntiles ints (ticket zero-initialised by the caller once; the kernel leaves it zero).
+extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket,
+                                   void* stream) {
+  using namespace vtp;
+  VTP_REQUIRE(probs && nprob >= 1 && nprob <= 8, "vtp_gemm_tn_grouped: 1..8 problems");
+  VTP_REQUIRE(ntiles >= 1 && K >= 64 && K % 8 == 0 && splits >= 1, "vtp_gemm_tn_grouped: bad shape (ntiles %d, K %d, splits %d)", ntiles, K, splits);
+  VTP_REQUIRE(splits == 1 || (part && ticket), "vtp_gemm_tn_grouped: split-K needs the partial-sum and ticket buffers");
+  GroupArgs ga{};
+  ga.probs = (const GroupProblem*)probs; ga.part = (float*)part; ga.ticket = (int*)ticket;
+  ga.nprob = nprob; ga.ntiles = ntiles; ga.K = K;
+  ga.k_split = ((K + splits - 1) / splits + 63) / 64 * 64;
+  ga.splits = (K + ga.k_split - 1) / ga.k_split;
+  ga.timing = g_p8_timing;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm8p_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm8p_grouped_tn_kernel, dim3(ntiles * ga.splits), dim3(512), P8_LDS, (hipStream_t)stream, ga);
+  return check_launch("gemm8p_grouped_tn");
+}
+
 // diagnostics for tools/gemm8p_timeline.py: `timing` = device buffer of [workgroups][16 tiles][4] u64 s_memrealtime stamps (100 MHz)
-// written by the 8-phase kernel (null: off); grid_limit caps its persistent grid (0: every CU)
-extern "C" int vtp_gemm_debug(void* timing, int grid_limit) {
+// written by the 8-phase kernel (null: off); grid_limit caps its persistent grid (0: every CU); delay_ticks > 0 starts every second
+// workgroup of an XCD that many 10-ns ticks late (is the chip's lock-step what serialises k loops and epilogue stores?)
+extern "C" int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks) {
   vtp::g_p8_timing = (unsigned long long*)timing;
   vtp::g_p8_grid = grid_limit;
+  vtp::g_p8_delay = delay_ticks;
   return VTP_OK;
 }

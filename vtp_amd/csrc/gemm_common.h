@@ -46,6 +46,7 @@ struct GemmArgs {
   int swiglu_ld;
   // diagnostics (vtp_gemm_debug): per workgroup and tile, s_memrealtime stamps {tile start, k loop done, epilogue issued}; null = off
   unsigned long long* timing;
+  int dbg_delay;  // diagnostics: every second workgroup (per XCD) starts this many 10-ns ticks late (lock-step experiments)
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,

@@ -274,6 +274,10 @@ WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
 # split-K weight gradients: private fp32 slabs + one reduce launch (default; bit-reproducible summation order) or fp32 atomics
 # straight into the flat gradient (VTP_WGRAD_ATOMIC=1)
 WGRAD_ATOMIC = _env_flag("VTP_WGRAD_ATOMIC", "0")  # measured: fp32 atomics from the MFMA epilogue halve the step rate
+# the four weight gradients of a transformer block as ONE grouped launch with the split-K combine and the bias-gradient column
+# sums inside it (ops.WgradGroup), issued one block late so that it runs beside the NEXT block's dgrad / attention kernels
+# (VTP_WGRAD_GROUPED=0: one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that layer's dgrad)
+WGRAD_GROUPED = _env_flag("VTP_WGRAD_GROUPED")
 
 
 def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
@@ -287,7 +291,7 @@ def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
                x_remap=(0, 0), dx_remap=(0, 0), gw=None, gb=None, N=None, K=None, wT=None, swiglu_h: int = 0,
-               bias_grad_done: bool = False, ls=None, dgrad_swiglu=None):
+               bias_grad_done: bool = False, ls=None, dgrad_swiglu=None, defer=None):
     """Backward of y[M,N] = x[M,K] W^T + b given dy (bf16 [M,N]):  dW += dy^T x,  db += colsum(dy),  dx = dy W.
     Reaches the NT GEMM through transposed operands: dy^T and x^T are produced by the LDS transpose kernel (the
     column sums for db ride along), W^T is the cached transposed weight.  The wgrad GEMM is split-K over the token
@@ -326,6 +330,9 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         return
     if bias_grad_done:  # the kernel that produced dy_b already accumulated its column sums into the bias gradient
         gb = None
+    if defer is not None:  # grouped weight gradients: record the problem, the caller launches the block's group later
+        assert dy_remap == (0, 0) and x_remap == (0, 0) and WGRAD_TN
+        defer.append(dict(dy=dy_b, x=x_b, gw=gw, gb=gb, N=N, K=K, swiglu_h=swiglu_h))
     Mp = pad8(M)
     c_remap = (-1, swiglu_h) if swiglu_h else (0, 0)
     S = ops.gemm_splits(Mp, _wgrad_splits(N, K, Mp))
@@ -362,7 +369,9 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
                         c_remap=c_remap)
             ops.reduce_slabs(slab, n_el, S, gw, n_el, accumulate=True)
 
-    if OVERLAP.enabled and need_dx:
+    if defer is not None:
+        pass
+    elif OVERLAP.enabled and need_dx:
         OVERLAP.join()   # previous layer's dW branch is done with the shared T.* scratch (and with its inputs)
         OVERLAP.fork()   # the side stream sees dy_b / x_b complete
         with torch.cuda.stream(OVERLAP.side):
@@ -510,24 +519,37 @@ class Stack:
             for (B, _, _), k in zip(segs, keeps):
                 idx[o:o + k] = torch.randperm(B, generator=generator)[:k].to(torch.int32)
                 o += k
-        return dict(idx=idx, keeps=keeps, scales=scales, per=per, ratio=ratio)
+        return dict(idx=idx, keeps=keeps, scales=scales, per=per, ratio=ratio, batches=[B for B, _, _ in segs])
 
     def set_drop_plan(self, plan, ws_key="drop"):
-        """activate / update (plan) or switch off (None) stochastic depth for the following forward + backward"""
+        """activate / update (plan) or switch off (None) stochastic depth for the following forward + backward.  The device index
+        buffer of a given size is allocated ONCE and kept for the lifetime of the stack: captured hipGraph segments bake its
+        address, so it is only ever refreshed in place -- switching the plan off, or alternating between plans of different sizes
+        (steps with / without SSL crops), never frees or moves a buffer a graph may still read."""
         if plan is None:
+            if self.drop_plan is not None:
+                self.last_drop_plan = self.drop_plan  # introspection (tests replay the subsets of the step that just ran)
             self.drop_plan = None
             return
         if self.qk_norm:
             raise NotImplementedError("stochastic depth together with QK normalisation is not built (the sample-drop branch runs the plain attention path)")
-        dev = self.store.device
-        cur = self.drop_plan
-        if cur is None or cur["idx_dev"].numel() != plan["idx"].numel():
-            cur = dict(plan)
-            cur["idx_dev"] = plan["idx"].to(dev)
-        else:  # same shapes: refresh the static index buffer in place (graph replay reads it)
-            cur["idx_dev"].copy_(plan["idx"], non_blocking=True)
-            cur.update(keeps=plan["keeps"], scales=plan["scales"], per=plan["per"], ratio=plan["ratio"])
+        bufs = self.__dict__.setdefault("_drop_bufs", {})
+        n = plan["idx"].numel()
+        buf = bufs.get(n)
+        if buf is None:
+            buf = bufs[n] = torch.empty(n, dtype=torch.int32, device=self.store.device)
+        buf.copy_(plan["idx"], non_blocking=True)
+        cur = dict(plan)
+        cur["idx_dev"] = buf
         self.drop_plan = cur
+
+    @staticmethod
+    def _check_drop_plan(p, segs):
+        """the plan was drawn for specific per-item batch sizes: a pass with other shapes must not run on it (out-of-range image
+        indices / silently truncated item lists)"""
+        got = [B for B, _, _ in segs]
+        if p.get("batches") != got:
+            raise RuntimeError(f"stochastic-depth plan drawn for item batch sizes {p.get('batches')} used on a pass with {got}")
 
     def _drop_idx(self, i: int, branch: int, s: int):
         p = self.drop_plan
@@ -540,6 +562,7 @@ class Stack:
         D, H, heads = self.D, self.H, self.heads
         p = self.drop_plan
         keeps, scales = p["keeps"], p["scales"]
+        self._check_drop_plan(p, segs)
         csegs = [(k, N, rp) for (B, N, rp), k in zip(segs, keeps)]  # the compact (gathered) list
         Mc = sum(k * N for k, N, _ in csegs)
         scale = 1.0 / math.sqrt(64.0)
@@ -604,6 +627,7 @@ class Stack:
         D, H, heads = self.D, self.H, self.heads
         p = self.drop_plan
         keeps, scales = p["keeps"], p["scales"]
+        self._check_drop_plan(p, segs)
         csegs = [(k, N, rp) for (B, N, rp), k in zip(segs, keeps)]
         Mc = sum(k * N for k, N, _ in csegs)
         scale = 1.0 / math.sqrt(64.0)
@@ -806,43 +830,65 @@ class Stack:
         M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
         vit = self.style == "vit"
+        # grouped weight gradients: the four dW of block i are ONE launch (split-K combine and bias-gradient column sums inside
+        # it), issued at the start of block i - 1's backward so that it overlaps that block's dgrad / attention kernels; the dy
+        # operands it reads (dpre, dmid_b, dqkv; dy_b already alternates) are therefore double-buffered by block parity
+        grouped = WGRAD_GROUPED and WGRAD_TN and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks)
+        par = (lambda i: f".{i & 1}") if grouped else (lambda i: "")
         dh = ws.get("b.dh", (M, H), BF)
-        dpre = ws.get("b.dx12", (M, 2 * H if vit else H), BF)
-        dxn = ws.get("b.dxn", (M, D), BF)
         d_o = ws.get("b.do", (M, D), BF)
-        dqkv = ws.get("b.dqkv", (M, 3 * D), BF)
+        dxn = ws.get("b.dxn", (M, D), BF)
         delta = ws.get("b.delta", (M * heads,), F32)
         dmid = ws.get("b.dmid", (M, D), F32)
-        dmid_b = ws.get("b.dmid_b", (M, D), BF)
         saved = self.last_saved if saved is None else saved
+        groups = ws.__dict__.setdefault("_wgrad_groups", {})
+        scratch = self.__dict__.setdefault("_wgrad_scratch", {})
+        pending = None  # (block index, ops.WgradGroup) whose launch is due
+
+        def launch_pending():
+            if pending is None:
+                return
+            if OVERLAP.enabled:
+                OVERLAP.fork()
+                with torch.cuda.stream(OVERLAP.side):
+                    pending[1].launch()
+            else:
+                pending[1].launch()
+
         for i in range(self.depth - 1, -1, -1):
             b = self.blocks[i]
             x_in, xn1, st1, qkv, o, lse, xmid, xn2, st2, pre, hid = saved[i]
             dxo = ws.get(f"b.dx{i & 1}", (M, D), F32)
             dxo_b = ws.get(f"b.dx_b{i & 1}", (M, D), BF)
+            dpre = ws.get("b.dx12" + par(i), (M, 2 * H if vit else H), BF)
+            dmid_b = ws.get("b.dmid_b" + par(i), (M, D), BF)
+            dqkv = ws.get("b.dqkv" + par(i), (M, 3 * D), BF)
+            probs = [] if grouped else None
+            if grouped:
+                launch_pending()  # dW of block i + 1, beside this block's kernels
             # ---- FFN: x_out = x_mid + w3(act(...))
-            fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1"
+            fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1" and not grouped
             fused_act = vit and FUSE_SWIGLU_BWD and b.ls2 is None and not fuse
             linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dpre if fused_act else dh,
                        bias_grad_done=dy_colsum_done if i == self.depth - 1 else self.w3_colsum_target(i) is not None,
-                       ls=(b.ls2, b.gls2) if b.ls2 is not None else None, dgrad_swiglu=pre if fused_act else None)
+                       ls=(b.ls2, b.gls2) if b.ls2 is not None else None, dgrad_swiglu=pre if fused_act else None, defer=probs)
             if vit:
                 if not fused_act:
                     # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
                     # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
                     ops.swiglu_bwd(dh, pre, dpre, M, H, db12=b.w12.gb1 if fuse else None)
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
-                           swiglu_h=H, bias_grad_done=fuse)
+                           swiglu_h=H, bias_grad_done=fuse, defer=probs)
             else:
                 ops.gelu_bwd(dh, pre, dpre, M * H)
-                linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn)
+                linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn, defer=probs)
             # the norm backward kernels also sum the columns of their bf16 output = the bias gradient of the linear layer that
             # takes it as dy (proj here; the previous block's w3 below)
             ops.norm_bwd(dxn, xmid, b.n2w, st2, dy, dmid, dmid_b, b.gn2w, b.gn2b, M, D, self.kind,
                          dx_colsum=b.proj.gb if b.ls1 is None else None)
             # ---- attention: x_mid = x_in + proj(attn(rope(qkv(xn1))))
             linear_bwd(ws, "proj", b.proj, dmid_b, o, M, d_o, bias_grad_done=b.proj.gb is not None,
-                       ls=(b.ls1, b.gls1) if b.ls1 is not None else None)
+                       ls=(b.ls1, b.gls1) if b.ls1 is not None else None, defer=probs)
             for r0, Bs, Ns, rp in self._attn_rows(segs):
                 r1 = r0 + Bs * Ns
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
@@ -853,12 +899,28 @@ class Stack:
             if b.qn_w is not None:  # gradient w.r.t. the normalised q, k -> w.r.t. the projection output (in place), + dw
                 ops.qk_norm_bwd(dqkv, ws.get(f"{i}.qkv_pre", (M, 3 * D), BF), ws.get(f"{i}.qinv", (M, 2 * heads), F32), b.qn_w, b.kn_w,
                                 b.g_qn, b.g_kn, M, D)
-            linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn)
+            linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, M, dxn, defer=probs)
+            if grouped:  # dW of block i + 1 is done: the norm backward below overwrites the dy operand it read (b.dx_b, same parity)
+                OVERLAP.join()
             ops.norm_bwd(dxn, x_in, b.n1w, st1, dmid, dxo, dxo_b, b.gn1w, b.gn1b, M, D, self.kind,
                          dx_colsum=self.w3_colsum_target(i - 1) if i > 0 else None)
             dy, dy_b = dxo, dxo_b
-            OVERLAP.join()
-            yield ("block", i)
+            if not grouped:
+                OVERLAP.join()
+                yield ("block", i)
+                continue
+            grp = groups.get(i)
+            if grp is None:
+                grp = ops.WgradGroup(M)
+                for pr in probs:
+                    grp.add(pr["dy"], pr["x"], pr["gw"], pr["gb"], pr["N"], pr["K"], pr["swiglu_h"])
+                groups[i] = grp.finalize(self.store.device, scratch)
+            if pending is not None:
+                yield ("block", pending[0])  # its weight gradients are complete (joined above)
+            pending = (i, grp)
+        if pending is not None:  # block 0's group: nothing of this stack is left to run beside it
+            pending[1].launch()
+            yield ("block", pending[0])
         return dy, dy_b
 
 

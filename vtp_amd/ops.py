@@ -151,6 +151,49 @@ def gemm_tn(a, b, c, *, M, N, K, lda, ldb, ldc, ldc2=0, resid=None, epi=EPI_F32,
     _lib.check(rc, "vtp_gemm_tn")
 
 
+class WgradGroup:
+    """The weight gradients of one transformer block as ONE launch (vtp_gemm_tn_grouped): problems dW_g[N_g, K_g] (+)= dy_g^T x_g
+    over the same token rows.  add() the problems, finalize() once (the operand buffers are static: the device descriptor table
+    is built a single time), launch() every step."""
+
+    def __init__(self, Ktok: int):
+        self.Ktok, self.rows, self.ntiles, self.keep = int(Ktok), [], 0, []
+        self.table = self.part = self.ticket = None
+
+    def add(self, dy, x, gw, gb, N: int, K: int, swiglu_h: int = 0, accumulate: bool = True):
+        """dy bf16 [Ktok, N] (row stride dy.stride(0)), x bf16 [Ktok, K], gw f32 [N * K], gb f32 [N] or None (bias gradient =
+        column sums of dy, fused).  swiglu_h: dy's columns are the 8|8-interleaved w1|w2 pre-activation gradients; the rows of gw
+        (and gb) are w1's H rows followed by w2's."""
+        assert N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+        self.rows.append([dy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), dy.stride(0), x.stride(0), K,
+                          N, K, -1 if swiglu_h else 0, swiglu_h, self.ntiles, int(accumulate), 0, 0, 0])
+        self.ntiles += ((N + 255) // 256) * ((K + 255) // 256)
+        self.keep += [dy, x, gw, gb]
+
+    def finalize(self, device, scratch=None):
+        """split factor: tiles x splits fills one round of the 256 CUs, every K slice keeps >= 16 k-tiles.  scratch: a dict shared by
+        the groups that never run concurrently (one partial-sum / ticket buffer for all of them)."""
+        import torch
+        assert 1 <= len(self.rows) <= 8
+        s = max(1, min(256 // self.ntiles, self.Ktok // 1024))
+        ks = ((self.Ktok + s - 1) // s + 63) // 64 * 64
+        self.splits = (self.Ktok + ks - 1) // ks
+        self.table = torch.tensor(self.rows, dtype=torch.int64, device=device)
+        if self.splits > 1:
+            scratch = {} if scratch is None else scratch
+            need = self.ntiles * self.splits * 65536
+            if scratch.get("part") is None or scratch["part"].numel() < need:
+                scratch["part"] = torch.empty(need, dtype=torch.float32, device=device)
+            if scratch.get("ticket") is None or scratch["ticket"].numel() < self.ntiles:
+                scratch["ticket"] = torch.zeros(max(self.ntiles, 256), dtype=torch.int32, device=device)
+            self.part, self.ticket = scratch["part"], scratch["ticket"]
+        return self
+
+    def launch(self):
+        _lib.check(_lib_().vtp_gemm_tn_grouped(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.splits, _p(self.part),
+                                                _p(self.ticket), _s()), "vtp_gemm_tn_grouped")
+
+
 def colsum_bf16(inp, ld, out, R, C, swiglu_h=0, in_remap=(0, 0)):
     _lib.check(_lib_().vtp_colsum_bf16(_p(inp), ld, _p(out), swiglu_h, in_remap[0], in_remap[1], R, C, _s()), "vtp_colsum_bf16")
 

@@ -742,11 +742,17 @@ class VTPTrainer:
         B, _, H, W = images.shape
         self._set_hyper()
         self._draw_drop_plans(B, ssl)
-        if self.use_graphs:
-            self._step_graphs(images, text, ssl)
-        else:
-            for ev in self._step_gen(images, text, ssl):
-                self._handle(ev)
+        try:
+            if self.use_graphs:
+                self._step_graphs(images, text, ssl)
+            else:
+                for ev in self._step_gen(images, text, ssl):
+                    self._handle(ev)
+        finally:
+            # the stochastic-depth plan belongs to THIS step: evaluation passes and the autograd path (get_intermediate_layers,
+            # TrunkTokens / EncodeLatents / SSLStudent) that follow must not run on its image subsets
+            self.trunk.stack.set_drop_plan(None)
+            self.decoder.stack.set_drop_plan(None)
         self.model._pver = self.model._param_version()
         return self.loss_sum / float(B * 3 * H * W), self.clip_loss_sum
 
@@ -801,8 +807,7 @@ class VTPTrainer:
         # values; lr / betas / weight decay / teacher temperature / EMA momentum live in device memory and are not part of the key
         baked = (self.clip_weight, self.rec_weight, self.perceptual_weight, self.student_temp, self.koleo_weight, self.centering,
                  self.teacher_temp if self.centering == "sinkhorn_knopp" else None, self.center_momentum)
-        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate > 0, self.decoder_drop_rate > 0,
-               baked)
+        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate, self.decoder_drop_rate, baked)
         plan = self._graphs.get(key)
         if plan is None:
             st = self.store
