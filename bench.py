@@ -349,16 +349,26 @@ def main():
         txt = synthetic_captions(B, model.config.text_context_length, model.config.text_vocab_size, dev, 4321 + rank) if clip else None
         return model, lp, trainer, txt
 
+    host_t = state.setdefault("host_t", [0.0, 0.0, 0.0])  # seconds of host time in: mask draw | prepare_ssl | step() enqueue
+
     def one_step(trainer, txt):
         """the step as a training loop runs it: fresh masks -> index plan -> H2D -> optimizer step"""
         ssl = None
+        t0 = time.perf_counter()
         if do_ssl:
             masks, upper = mask_stream.draw()
+            t1 = time.perf_counter()
             ssl = trainer.prepare_ssl(crops[0], crops[1], masks, upperbound=upper)
             state["n_masked"].append(ssl["plan"]["n_masked"])
             state["Ts"].add(ssl["plan"]["Ts"])
             state["last_plan"] = ssl["plan"]
-        return trainer.step(img, txt, ssl)
+            t2 = time.perf_counter()
+            host_t[0] += t1 - t0
+            host_t[1] += t2 - t1
+            t0 = t2
+        out = trainer.step(img, txt, ssl)
+        host_t[2] += time.perf_counter() - t0
+        return out
 
     def sync():
         if world > 1:
@@ -383,9 +393,12 @@ def main():
             sync()
         trainer.time_comm = world > 1  # HIP events around every point where the main stream waits for a collective
         trainer.bucketer.comm_bytes = 0
+        host_t[:] = [0.0, 0.0, 0.0]
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, closs = one_step(trainer, txt)
+        state["host_split_ms"] = [round(v * 1e3 / steps, 3) for v in host_t]
+        state["host_ms_per_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)  # enqueue time: << ms_per_step unless host-bound
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -401,6 +414,7 @@ def main():
         return model, lp, trainer, txt, launch, elapsed, loss, closs
 
     model, lp, trainer, txt, launch, elapsed, loss, closs = measure(args.perceptual_weight, args.steps, args.warmup)
+    state["host_ms_main"], state["host_split_main"] = state.get("host_ms_per_step"), state.get("host_split_ms")
     state["comm_main"] = state.pop("comm", None)  # rank 0's main-stream waits (the second, LPIPS-on measurement overwrites "comm")
     ssl = None
     if do_ssl:  # the instrumented step below reuses the last drawn batch
@@ -555,7 +569,7 @@ def main():
                    "launch": launch, "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}" + ("" if backend == "nccl" else f" ({backend} rehearsal, shared GPU)"),
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
-        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "ssl": ssl_info, "lpips": lpips_info, "lpips_on": lpips_on,
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "host_enqueue_ms_per_step": state.get("host_ms_main"), "host_split_ms": state.get("host_split_main"), "ssl": ssl_info, "lpips": lpips_info, "lpips_on": lpips_on,
         "comm": state.get("comm_main"),
         "step_tflops_per_gpu": round(ips / world * gflop_img / 1e3, 1),
         "step_frac": round(ips / world * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4),

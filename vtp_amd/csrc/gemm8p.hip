@@ -43,8 +43,6 @@ __device__ __forceinline__ void p8_wait_vm_halftiles(int n) {  // at most n (0..
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// VAR (experiment switches, 0 = shipped schedule): bit 0 = no group stagger | bit 1 = no s_setprio around the MFMA segments |
-// bit 2 = LDS-DMA pieces issued between the MFMAs of the segment instead of in the load segment
 // LDS-DMA of 16 B per lane with a scalar 64-bit base + a 32-bit lane offset (no vector address arithmetic), M0 = LDS
 // destination of the wave's 1-KiB piece.  Inline asm because hipcc turns the "tail or not" choice of the source pointer into a
 // per-lane 64-bit select in front of every piece otherwise; its completion is counted by hand (the vmcnt waits below).
@@ -53,6 +51,15 @@ __device__ __forceinline__ void p8_glds16(const char* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// the same with a per-lane 64-bit source address (K tails: lanes past the end read the zero block)
+__device__ __forceinline__ void p8_glds16_v(const char* vaddr, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(vaddr), "s"(lds_dst)
                : "memory");
 }
 
@@ -76,9 +83,8 @@ struct GroupTile {
   int tile, splits;
 };
 
-template <int EPI, bool TRANS, int VAR = 0>
+template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
 __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslice, const int G, const bool flat, const GroupTile gt) {
-  constexpr bool STAGGER = !(VAR & 1), SETPRIO = !(VAR & 2), DMA_IN_MMA = (VAR & 4) != 0;
   // VAR bit 3: the operands are fp8 (e4m3, OCP) -- same bytes, same staging, same fragment reads (the launcher passes K and the
   // leading dimensions in 2-byte units); only the MFMA changes: v_mfma_f32_32x32x64_f8f6f4 takes 32 B per lane, i.e. two of
   // the 16-B fragments, and A and B use the same (fragment, byte) -> k-slot map, so the dot products pair up the right elements
@@ -171,9 +177,10 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       p8_glds16(base, off[J][i], s_dst + i * 1024);
     } else {  // K tail (the last k-tile of a tile only): zero-fill per lane
       const int krem = kend - kbeg - s_kt * 64;
+      // inline asm like the fast path: ONE compiler-visible LDS-DMA in this loop makes hipcc drain `vmcnt(0)` in front of the
+      // fragment reads of every k-tile (it cannot see the asm pieces, so its own count of what is in flight is always "this one")
       const char* z = (kq[i] < krem) ? base + off[J][i] : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)z,
-                                       (__attribute__((address_space(3))) void*)(size_t)(s_dst + i * 1024), 16, 0, 0);
+      p8_glds16_v(z, s_dst + i * 1024);
     }
   };
   auto advance = [&](auto jt) {
@@ -285,34 +292,23 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
   zero_acc();
-  // one MFMA segment: a 64 x 32 quadrant x k = 64.  jt: with DMA_IN_MMA the two LDS-DMA pieces of the half-tile under the
-  // staging cursor are issued behind the 2nd and the 6th MFMA (their issue cost hides under the matrix pipe)
-  auto mma2 = [&](f32x16& c0, f32x16& c1, const Frags& w, const Frags& x0, const Frags& x1, auto jt) {
-    const bool dma = DMA_IN_MMA && s_h < H;
-    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);
+  // one MFMA segment: a 64 x 32 quadrant x k = 64, at raised priority (the partner wave on this SIMD is in its load segment)
+  auto mma2 = [&](f32x16& c0, f32x16& c1, const Frags& w, const Frags& x0, const Frags& x1) {
+    __builtin_amdgcn_s_setprio(1);
     if constexpr (FP8) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.g[kk], x0.g[kk], c0, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3; zero scale operands select the unscaled v_mfma_f32_32x32x64_f8f6f4
         c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.g[kk], x1.g[kk], c1, 0, 0, 0, 0, 0, 0);
       }
-    } else
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x0.f[ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x1.f[ks], c1, 0, 0, 0);
-      if constexpr (DMA_IN_MMA) {
-        if (ks == 0 || ks == 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (dma) issue_piece(jt, ks >> 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int ks = 0; ks < 4; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x0.f[ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[ks], x1.f[ks], c1, 0, 0, 0);
       }
     }
-    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);
-    if constexpr (DMA_IN_MMA) {
-      if (dma) advance(jt);
-    }
+    __builtin_amdgcn_s_setprio(0);
   };
   auto seg_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -350,7 +346,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
     tile_origin(ti, m0, n0);
     stamp(ti, 0);
     if constexpr (TRANS) do_csum = p.colsum != nullptr && wc == 0 && n0 == 0;
-    if (STAGGER && wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
+    if (wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       Frags b1, b2, a1[2], a2[2];
@@ -359,13 +355,13 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       __builtin_amdgcn_sched_barrier(0);
       load_a(kb + P8_SLOT, a1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!DMA_IN_MMA && s_h < H) issue(I3{});
+      if (s_h < H) issue(I3{});
       __builtin_amdgcn_sched_barrier(0);
       // the B-first reads (issued first) are done: phase 1 overwrites that slot (TN: 8 + 16 tr reads, the counter holds 15)
       if constexpr (!TRANS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
       seg_barrier();
-      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1], I3{});
+      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1]);
       if constexpr (TRANS) {
         if (do_csum) add_csum(a1, 0);
       }
@@ -373,28 +369,28 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63)
       load_b(kb + 2 * P8_SLOT, b2);
       __builtin_amdgcn_sched_barrier(0);
-      if (!DMA_IN_MMA && s_h < H) issue(I0{});
+      if (s_h < H) issue(I0{});
       seg_barrier();
-      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1], I0{});
+      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
       seg_barrier();
       // ---- phase 2: A-second -> quadrant (cols 32..63, rows 64..127)
       load_a(kb + 3 * P8_SLOT, a2);
       __builtin_amdgcn_sched_barrier(0);
-      if (!DMA_IN_MMA && s_h < H) issue(I1{});
+      if (s_h < H) issue(I1{});
       seg_barrier();
-      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1], I1{});
+      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
       if constexpr (TRANS) {
         if (do_csum) add_csum(a2, 2);
       }
       seg_barrier();
       // ---- phase 3: quadrant (cols 0..31, rows 64..127); the next k-tile's four half-tiles must have landed
-      if (!DMA_IN_MMA && s_h < H) issue(I2{});
+      if (s_h < H) issue(I2{});
       p8_wait_vm_halftiles(s_h - 4 * (ktg + 2));
       seg_barrier();
-      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1], I2{});
+      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
       seg_barrier();
     }
-    if (STAGGER && wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
+    if (wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
     stamp(ti, 1);
     if constexpr (TRANS) {
       if (do_csum) {
@@ -465,13 +461,13 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       }
     }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
-    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
+    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION, XMODE>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
     stamp(ti, 2);
     zero_acc();
   }
 }
 
-template <int EPI, bool TRANS, int VAR = 0>
+template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
   // split-K launches arrive as ONE flat grid of ntiles x splits workgroups (bit 2 of xcd_swizzle): workgroups are dealt to the 8
   // XCDs round-robin, and XCD x takes a contiguous chunk of the (split-major) list -- so the tiles that stream the same K slice of
@@ -485,7 +481,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     zslice = c / ntiles;
     bx = c - zslice * ntiles;
   }
-  gemm8p_body<EPI, TRANS, VAR>(p, bx, zslice, flat ? ntiles : (int)gridDim.x, flat, GroupTile{nullptr, nullptr, 0, 1});
+  gemm8p_body<EPI, TRANS, VAR, XMODE>(p, bx, zslice, flat ? ntiles : (int)gridDim.x, flat, GroupTile{nullptr, nullptr, 0, 1});
 }
 
 // Grouped weight gradients: up to 8 problems C_g[M_g, N_g] (+)= A_g[K, M_g]^T B_g[K, N_g] over the SAME K token rows (the four linear
@@ -535,12 +531,12 @@ __global__ __launch_bounds__(512) void gemm8p_grouped_tn_kernel(const GroupArgs 
 static unsigned long long* g_p8_timing = nullptr;
 static int g_p8_grid = 0, g_p8_delay = 0;
 
-template <int EPI, bool TRANS, int VAR = 0>
+template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
 static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
   GemmArgs a = a0;
   a.timing = g_p8_timing;
   a.dbg_delay = g_p8_delay;
-  auto kern = gemm8p_kernel<EPI, TRANS, VAR>;
+  auto kern = gemm8p_kernel<EPI, TRANS, VAR, XMODE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
@@ -556,8 +552,7 @@ static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
     if (cus < 8) cus = 8;
   }
   const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 256);
-  static const bool flat_ok = !(getenv("VTP_GEMM_FLAT_SPLIT") && atoi(getenv("VTP_GEMM_FLAT_SPLIT")) == 0);
-  if (splits > 1 && flat_ok) {
+  if (splits > 1) {
     GemmArgs f = a;
     f.xcd_swizzle |= 4;
     hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(512), P8_LDS, s, f);
@@ -581,16 +576,10 @@ bool gemm8p_fits(const GemmArgs& a, bool trans) {
 // entry points used by the dispatchers of gemm.hip
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: {
-      static const int var = getenv("VTP_GEMM8P_VAR") ? atoi(getenv("VTP_GEMM8P_VAR")) : 0;  // schedule experiments (tools/)
-      switch (var) {
-        case 1: return launch8p<EPI_BF16, false, 1>(a, 1, s);
-        case 2: return launch8p<EPI_BF16, false, 2>(a, 1, s);
-        case 4: return launch8p<EPI_BF16, false, 4>(a, 1, s);
-        case 6: return launch8p<EPI_BF16, false, 6>(a, 1, s);
-        default: return launch8p<EPI_BF16, false>(a, 1, s);
-      }
-    }
+    case EPI_BF16:  // the fused extras of the LDS-staged store path are separate instantiations (gemm_epilogue XMODE)
+      if (a.rope_pos) return launch8p<EPI_BF16, false, 0, 1>(a, 1, s);
+      if (a.swiglu_pre) return launch8p<EPI_BF16, false, 0, 2>(a, 1, s);
+      return launch8p<EPI_BF16, false, 0, 0>(a, 1, s);
     case EPI_F32: return launch8p<EPI_F32, false>(a, 1, s);
     case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false>(a, 1, s);
     case EPI_GELU: return launch8p<EPI_GELU, false>(a, 1, s);
@@ -603,7 +592,7 @@ int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 // fp8 (e4m3) operands, NT, forward epilogues only; `a` carries K, lda, ldb in 2-byte units (see the kernel's FP8 note)
 int launch_gemm8p_nt_fp8(const GemmArgs& a, int epi, hipStream_t s) {
   switch (epi) {
-    case EPI_BF16: return launch8p<EPI_BF16, false, 8>(a, 1, s);
+    case EPI_BF16: return a.rope_pos ? launch8p<EPI_BF16, false, 8, 1>(a, 1, s) : launch8p<EPI_BF16, false, 8, 0>(a, 1, s);
     case EPI_F32: return launch8p<EPI_F32, false, 8>(a, 1, s);
     case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false, 8>(a, 1, s);
     default: set_error("gemm8p fp8: unsupported epilogue %d", epi); return VTP_ERR_ARG;
@@ -613,8 +602,6 @@ int launch_gemm8p_nt_fp8(const GemmArgs& a, int epi, hipStream_t s) {
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   if (epi == EPI_F32) return launch8p<EPI_F32, true>(a, 1, s);
   if (epi == EPI_F32_ATOMIC) return launch8p<EPI_F32_ATOMIC, true>(a, splits, s);
-  static const int var = getenv("VTP_GEMM8P_VAR") ? atoi(getenv("VTP_GEMM8P_VAR")) : 0;
-  if (var == 4) return launch8p<EPI_F32_SLAB, true, 4>(a, splits, s);
   return launch8p<EPI_F32_SLAB, true>(a, splits, s);
 }
 
@@ -627,7 +614,7 @@ extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int
                                    void* stream) {
   using namespace vtp;
   VTP_REQUIRE(probs && nprob >= 1 && nprob <= 8, "vtp_gemm_tn_grouped: 1..8 problems");
-  VTP_REQUIRE(ntiles >= 1 && K >= 64 && K % 8 == 0 && splits >= 1, "vtp_gemm_tn_grouped: bad shape (ntiles %d, K %d, splits %d)", ntiles, K, splits);
+  VTP_REQUIRE(ntiles >= 1 && K >= 1 && splits >= 1, "vtp_gemm_tn_grouped: bad shape (ntiles %d, K %d, splits %d)", ntiles, K, splits);
   VTP_REQUIRE(splits == 1 || (part && ticket), "vtp_gemm_tn_grouped: split-K needs the partial-sum and ticket buffers");
   GroupArgs ga{};
   ga.probs = (const GroupProblem*)probs; ga.part = (float*)part; ga.ticket = (int*)ticket;

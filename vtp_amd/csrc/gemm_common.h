@@ -78,11 +78,17 @@ __device__ __forceinline__ bool gemm_epilogue_uses_lds(const GemmArgs& p) {
 // of the output tile at (m0, n0); the wave's sub-tile starts at row wm * WTM, column wn * WTN.  MFMA operands were swapped
 // (weight rows = A operand), so a lane holds, for output row m = .. + (lane & 31), columns nb + 8*q + 4*hi + (0..3), q = 0..3.
 // reg: this wave's private LDS staging region of REGION bytes (or null: direct stores).
-template <int EPI, bool TRANS, int WTM, int WTN, int REGION>
+// XMODE (bf16 epilogue only): which fused extra the LDS-staged store path carries -- -1: decided at run time from the argument block
+// (the ring kernels) | 0: none | 1: apply_rope (rope_pos) | 2: SwiGLU backward (swiglu_pre).  The 256 x 256 kernel instantiates
+// 0 / 1 / 2 separately: the plain variant then carries neither the extras' registers (the pre-activation prefetch alone is 32)
+// nor conditionally waited loads that make hipcc drain `vmcnt(0)` at the head of the k loop.
+template <int EPI, bool TRANS, int WTM, int WTN, int REGION, int XMODE = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[WTN / 32][WTM / 32], char* reg, int m0, int n0,
                                               int wm, int wn, int lane, int zslice = blockIdx.z) {
   constexpr int TM = WTM / 32, TN = WTN / 32;
   const int hi = lane >> 5;
+  const bool x_rope = XMODE < 0 ? p.rope_pos != nullptr : XMODE == 1;
+  const bool x_swiglu = XMODE < 0 ? p.swiglu_pre != nullptr : XMODE == 2;
   // ---- epilogue: lane holds, for output row m, columns nb + 8*q + 4*hi + (0..3), q = 0..3 ----
   // bf16 outputs go through LDS so that the global stores are full 128/256-B row segments (16 B per lane, consecutive lanes
   // = consecutive addresses) instead of 8-B pieces of 32 different rows per instruction: each wave transposes 32-row
@@ -100,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
         // fused SwiGLU backward: this block's x1 | x2 pre-activations are requested BEFORE the accumulators go through LDS, so the
         // loads fly while the block is transposed (they are consumed in the store loop below)
         bf16x8 sx1[TPB], sx2[TPB];
-        if (p.swiglu_pre) {
+        if (x_swiglu) {
 #pragma unroll
           for (int t = 0; t < TPB; ++t) {
             const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
@@ -126,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
           bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
           const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
-          if (p.rope_pos && n0 + wn * WTN < p.rope_cols) {  // wave-uniform: this wave's columns are q / k heads
+          if (x_rope && n0 + wn * WTN < p.rope_cols) {  // wave-uniform: this wave's columns are q / k heads
             // a head is 8 consecutive 16-B chunks of the row image: the partner element d +- 32 sits in chunk c ^ 4 = lane ^ 4.
             // out = x*cos + rot_half(x)*sin with the three eager-bf16 roundings of the reference (rope_qk_kernel, bit-identical)
             typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -145,7 +151,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
                 val[e] = f2bf(bf2f(f2bf(bf2f(val[e]) * bf2f(cs[e]))) + bf2f(f2bf(sg * bf2f(prt[e]) * bf2f(sn[e]))));
             }
           }
-          if (p.swiglu_pre) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
+          if (x_swiglu) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
             if (m < p.M && n < p.N) {
               const bf16x8 x1 = sx1[t], x2 = sx2[t];
               bf16x8 o1, o2;
