@@ -111,3 +111,20 @@ def test_extract_features_shards_and_stats(tok, tmp_path):
     ref = TO.latent_stats(torch.cat([d0["latents"], d1["latents"]]))
     assert st["mean"].shape == (1, tok.embed_dim, 1, 1)
     assert torch.allclose(st["mean"], ref["mean"], rtol=1e-5, atol=1e-6) and torch.allclose(st["std"], ref["std"], rtol=1e-5, atol=1e-6)
+
+
+def test_img_transform_matches_device_path(tok):
+    """VTP_Tokenizer.img_transform (the reference's dataset transform, vtp_tokenizer.py:74-81) as a host callable == crop_to_u8 +
+    images_from_u8 on the device, bit for bit; transform_inv undoes the normalisation"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    pil = Image.fromarray(rng.integers(0, 256, (90, 130, 3), dtype=np.uint8))
+    size = tok.img_size
+    host = tok.img_transform(p_hflip=0)(pil)
+    dev = tok.images_from_u8(tok.crop_to_u8(pil, size)[None])[0].cpu()
+    assert host.shape == (3, size, size) and torch.equal(host, dev)
+    flipped = tok.img_transform(p_hflip=1.0)(pil)
+    assert torch.equal(flipped, tok.images_from_u8(tok.crop_to_u8(pil, size)[None], flip=True)[0].cpu())
+    back = tok.transform_inv(host)
+    u8 = torch.from_numpy(tok.crop_to_u8(pil, size).copy()).permute(2, 0, 1).float() / 255
+    assert float((back - u8).abs().max()) < 1e-6

@@ -12,7 +12,8 @@ requires grad keeps the Functions on the autograd tape.
 
 Static workspaces mean ONE forward per (tower, tag, shape) can wait for its backward; a later forward of the same kind
 overwrites the saved activations and a backward through the earlier one raises (see _Flight).
-The small heads on top (cls / mean pooling, visual_proj, F.normalize, logits) are ordinary torch ops on the fp32 parameters.
+The small heads on top (cls / mean pooling, bottleneck, visual_proj, F.normalize, logits) are kernel-backed Functions as well
+(HeadLinear / SumTokens / L2Normalize / ClipLogits at the end of this file).
 """
 from __future__ import annotations
 
@@ -238,3 +239,113 @@ class SSLStudent(torch.autograd.Function):
         ops.scatter_token_rows(dX[nl:], idx["student_global_src"], d_xnf[seg_g.row0:], Ts - nl, D)
         _drain(tr.backward(None, ctx=tctx))
         return None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------- feature heads
+# The [B, D]-sized heads behind get_clip_image_feature / get_clip_logits (modeling_vtp.py:244-333): bottleneck / visual_proj
+# projections, token pooling, F.normalize and the logit matrix -- on the same kernels as the fused trainer (bf16 MFMA GEMM with
+# fp32 accumulation = what the reference's Linear layers do under bf16 autocast), each with a hand-written backward.
+def _ws(model):
+    return model._clip.ws
+
+
+class HeadLinear(torch.autograd.Function):
+    """y f32 [R, N] = alpha * bf16(x) W^T for a bias-free projection held by the engine (`lin`: engine.Lin with bf16 W / W^T copies
+    and the flat-gradient view); backward: dx = alpha * dy W, dW += alpha * dy^T x accumulated into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, anchor_, model, lin, alpha):
+        st = model._fresh()
+        st.sync_grad_views()
+        R, K = x.shape
+        assert K == lin.K
+        x_b = torch.empty(R, K, dtype=BF, device=x.device)
+        ops.cast_f32_bf16(x.contiguous().float(), x_b, R * K)
+        y = torch.empty(R, lin.N, dtype=F32, device=x.device)
+        ops.gemm_nt(x_b, lin.w, y, M=R, N=lin.N, K=K, epi=ops.EPI_F32, alpha=alpha)
+        ctx.model, ctx.lin, ctx.alpha, ctx.x_b = model, lin, alpha, x_b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lin, x_b = ctx.lin, ctx.x_b
+        ctx.model._store.sync_grad_views()
+        R, K = x_b.shape
+        dy_b = torch.empty(R, lin.N, dtype=BF, device=dy.device)
+        ops.cast_f32_bf16(dy.contiguous().float(), dy_b, R * lin.N)
+        dx = torch.empty(R, K, dtype=F32, device=dy.device)
+        ops.gemm_nt(dy_b, lin.wT, dx, M=R, N=K, K=lin.N, epi=ops.EPI_F32, alpha=ctx.alpha)
+        if ctx.alpha != 1.0:  # dW += alpha * dy^T x: fold alpha into dy (one more rounding of a [R, N] matrix)
+            ops.cast_f32_bf16((dy * ctx.alpha).contiguous().float(), dy_b, R * lin.N)
+        ops.gemm_tn(dy_b, x_b, lin.gw, M=lin.N, N=K, K=R, lda=lin.N, ldb=K, ldc=K, resid=lin.gw, epi=ops.EPI_F32)
+        return dx, None, None, None, None
+
+
+class SumTokens(torch.autograd.Function):
+    """tokens f32 [B, n, D] -> their sum over n, f32 [B, D] (the mean pooling of vision_clip_feat = 'pooled'; the 1 / n rides in the
+    following projection's alpha)"""
+
+    @staticmethod
+    def forward(ctx, tokens):
+        B, n, D = tokens.shape
+        t = tokens.contiguous().float()
+        out = torch.zeros(B, D, dtype=F32, device=t.device)
+        for b in range(B):
+            ops.strided_rowsum(t[b], D, out[b], n, D)
+        ctx.shape = (B, n, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, n, D = ctx.shape
+        return d[:, None, :].expand(B, n, D).contiguous()
+
+
+class L2Normalize(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (eps 1e-12) on the l2norm kernels"""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, D = x.shape
+        x = x.contiguous().float()
+        y, inv = torch.empty_like(x), torch.empty(B, dtype=F32, device=x.device)
+        ops.l2norm_fwd(x, y, inv, B, D, 1e-12)
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        ops.l2norm_bwd(dy.contiguous().float(), y, inv, dx, y.shape[0], y.shape[1])
+        return dx
+
+
+class ClipLogits(torch.autograd.Function):
+    """logits f32 [M, N] = exp(logit_scale) * I T^T (modeling_vtp.py:326-329) on the clip_logits kernel; backward through the
+    clip_grad_rows / clip_grad_cols kernels, d logit_scale = sum(dL . logits)"""
+
+    @staticmethod
+    def forward(ctx, i, t, logit_scale):
+        i, t = i.contiguous().float(), t.contiguous().float()
+        M, D = i.shape
+        N = t.shape[0]
+        out = torch.empty(M, N, dtype=F32, device=i.device)
+        ops.clip_logits(i, t, logit_scale.detach().reshape(1), out, M, N, D)
+        ctx.save_for_backward(i, t, logit_scale.detach().reshape(1), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dL):
+        i, t, ls, logits = ctx.saved_tensors
+        M, D = i.shape
+        N = t.shape[0]
+        G = dL.contiguous().float()
+        di, dt = torch.empty_like(i), torch.empty_like(t)
+        L = ops._lib_()
+        from . import _lib
+        s = ops._s()
+        _lib.check(L.vtp_clip_grad_rows(ops._p(G), ops._p(t), ops._p(ls), ops._p(di), M, N, D, 0, s), "vtp_clip_grad_rows")
+        _lib.check(L.vtp_clip_grad_cols(ops._p(G), ops._p(i), ops._p(ls), ops._p(dt), M, N, D, 0, s), "vtp_clip_grad_cols")
+        d_ls = torch.dot(G.reshape(-1), logits.reshape(-1)).reshape(())
+        return di, dt, d_ls

@@ -504,12 +504,16 @@ class Stack:
         alloc = [min(base + (1 if i < extra else 0), b) for i in range(world)]
         return alloc[rank], gb / max(sum(alloc), 1)
 
-    def make_drop_plan(self, segs, ratio: float, generator: Optional[torch.Generator] = None, world: int = 1, rank: int = 0):
-        """Host side, once per step: a random image subset per (block, branch, list item).  Returns a dict with the int32 index
-        tensor (CPU; copy it into the static device buffer with set_drop_plan) and the static shape information."""
+    def make_drop_plan(self, segs, ratio, generator: Optional[torch.Generator] = None, world: int = 1, rank: int = 0):
+        """Host side, once per step: a random image subset per (block, branch, list item).  `ratio`: one rate, or one per list item
+        (the reference has a rate per objective -- clip_drop_rate / ssl_drop_rate / rec_drop_rate, vtp.py:205-207 -- and the
+        objectives are items of one list forward here).  Returns a dict with the int32 index tensor (CPU; copy it into the static
+        device buffer with set_drop_plan) and the static shape information."""
+        ratios = list(ratio) if isinstance(ratio, (list, tuple)) else [ratio] * len(segs)
+        assert len(ratios) == len(segs)
         keeps, scales = [], []
-        for B, _, _ in segs:
-            k, sc = self.drop_allocation(B, ratio, world, rank)
+        for (B, _, _), r in zip(segs, ratios):
+            k, sc = self.drop_allocation(B, r, world, rank)
             keeps.append(k)
             scales.append(sc)
         per = sum(keeps)

@@ -439,8 +439,9 @@ class VTPModel(nn.Module):
         c = self.config
         general = c.vision_clip_feat != "cls" or not c.vision_bottleneck_ae_only
         if ag.grad_mode(self) or general:
-            # tokens from the trunk kernels; the [B, D] pooling / projection / normalisation heads are torch ops on the fp32
-            # parameters (autograd-native; the reference does the same arithmetic, modeling_vtp.py:262-276)
+            # tokens from the trunk kernels; the [B, D] pooling / projection / normalisation heads on kernels too (autograd.HeadLinear /
+            # SumTokens / L2Normalize: the arithmetic of modeling_vtp.py:262-276, bf16 MFMA with fp32 accumulation like the
+            # reference's Linear layers under bf16 autocast)
             self._img(image)
             if ag.grad_mode(self):
                 tokens = ag.TrunkTokens.apply(image, ag.anchor(self), self, "ag.clip")
@@ -450,13 +451,15 @@ class VTPModel(nn.Module):
                     img = self._img(image)
                     tokens = self._trunk.forward(img, train=False).float().view(img.shape[0], -1, c.vision_embed_dim)
             with torch.set_grad_enabled(ag.grad_mode(self)):
-                pooled, patches = tokens[:, 0], tokens[:, 1:]
-                if not c.vision_bottleneck_ae_only and hasattr(self.trunk, "feature_bottleneck"):
-                    wb = self.trunk.feature_bottleneck.weight
-                    pooled, patches = torch.nn.functional.linear(pooled, wb), torch.nn.functional.linear(patches, wb)
-                feat = pooled if c.vision_clip_feat == "cls" else patches.mean(dim=1)
-                feat = torch.nn.functional.linear(feat, self.visual_proj.weight)
-                return torch.nn.functional.normalize(feat, dim=-1) if normalize else feat
+                a = ag.anchor(self)
+                if c.vision_clip_feat == "cls":
+                    feat, scale = tokens[:, 0], 1.0
+                else:  # mean over the patch tokens: the sum here, 1 / hw in the next projection (linear maps commute with the mean)
+                    feat, scale = ag.SumTokens.apply(tokens[:, 1:]), 1.0 / (tokens.shape[1] - 1)
+                if not c.vision_bottleneck_ae_only and self._trunk.bott is not None:
+                    feat, scale = ag.HeadLinear.apply(feat, a, self, self._trunk.bott, scale), 1.0
+                feat = ag.HeadLinear.apply(feat, a, self, self._vproj, scale)
+                return ag.L2Normalize.apply(feat) if normalize else feat
         return self._clip_image_nograd(image, normalize)
 
     @torch.no_grad()
@@ -480,7 +483,7 @@ class VTPModel(nn.Module):
         if ag.grad_mode(self):
             ids = self._ids(text)
             f = ag.TextFeature.apply(ids, ag.anchor(self), self)
-            return torch.nn.functional.normalize(f, dim=-1) if normalize else f
+            return ag.L2Normalize.apply(f) if normalize else f
         return self._clip_text_nograd(text, normalize)
 
     @torch.no_grad()
@@ -494,11 +497,11 @@ class VTPModel(nn.Module):
 
     def get_clip_logits(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """modeling_vtp.py:312-333.  Inference: the [B_img, B_txt] logits come from the clip_logits kernel (exp(logit_scale) * I T^T,
-        fp32); in training mode they are torch ops on the two differentiable feature matrices (autograd needs them on the tape)."""
+        fp32); in training mode the same kernel inside autograd.ClipLogits (backward on the clip_grad kernels)."""
         i = self.get_clip_image_feature(image, normalize=True)
         t = self.get_clip_text_feature(text, normalize=True)
         if ag.grad_mode(self):
-            logits = self.logit_scale.exp() * i @ t.T
+            logits = ag.ClipLogits.apply(i, t, self.logit_scale)
         else:
             logits = torch.empty(i.shape[0], t.shape[0], dtype=torch.float32, device=i.device)
             ops.clip_logits(i.contiguous(), t.contiguous(), self._store.p("logit_scale"), logits, i.shape[0], t.shape[0], i.shape[1])

@@ -67,6 +67,29 @@ class VTP_Tokenizer:
         self.inv_mean = [-m / s for m, s in zip(self.norm_mean, self.norm_std)]
         self.inv_std = [1.0 / s for s in self.norm_std]
 
+    def img_transform(self, p_hflip: float = 0, img_size: Optional[int] = None):
+        """The reference's dataset transform (vtp_tokenizer.py:74-81: center_crop_arr -> RandomHorizontalFlip(p) -> ToTensor ->
+        Normalize) as a plain callable PIL image -> f32 [3, S, S] on the host (torchvision is not a dependency here; ImageFolder
+        only needs a callable).  Same fp32 op order as torchvision: x / 255, then (x - mean) / std.  Batches on the device go through
+        `crop_to_u8` + `images_from_u8` (one kernel instead)."""
+        size = self.img_size if img_size is None else img_size
+        mean = torch.tensor(self.norm_mean, dtype=torch.float32).view(3, 1, 1)
+        std = torch.tensor(self.norm_std, dtype=torch.float32).view(3, 1, 1)
+
+        def transform(pil_image):
+            u8 = torch.from_numpy(self.crop_to_u8(pil_image, size).copy())          # [S, S, 3]
+            if p_hflip > 0 and float(torch.rand(1)) < p_hflip:
+                u8 = u8.flip(1)
+            x = u8.permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+            return x.sub_(mean).div_(std)
+        return transform
+
+    def transform_inv(self, x: torch.Tensor) -> torch.Tensor:
+        """vtp_tokenizer.py:67-72: Normalize(-mean / std, 1 / std), i.e. x * std + mean in the reference's op order"""
+        m = torch.tensor(self.inv_mean, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        sd = torch.tensor(self.inv_std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        return (x - m) / sd
+
     # ---- host side of img_transform (vtp_tokenizer.py:74-81): crop on the host, the rest on the device
     def crop_to_u8(self, pil_image, img_size: Optional[int] = None) -> np.ndarray:
         """PIL image -> uint8 [S, S, 3] (RGB) centre crop; feed batches of these to `images_from_u8`."""

@@ -219,16 +219,21 @@ class VTPTrainer:
                  rec_weight: float = 1.0, dino_weight: float = 1.0, ibot_weight: float = 1.0, student_temp: float = 0.1,
                  teacher_temp: float = 0.07, center_momentum: float = 0.9, teacher_momentum: float = 0.994,
                  lpips=None, perceptual_weight: float = 0.0, drop_rate: float = 0.0, decoder_drop_rate: float = 0.0,
+                 clip_drop_rate: Optional[float] = None, ssl_drop_rate: Optional[float] = None, rec_drop_rate: Optional[float] = None,
                  drop_seed: int = 0, centering: str = "softmax", koleo_weight: float = 0.0, sk_iterations: int = 3,
                  shard_optimizer: Optional[bool] = None, grad_dtype: str = "fp32", no_decay="default",
                  force_collectives: bool = False):
         """lpips: a vtp_amd.LPIPS module (frozen, weights loaded by the caller) -- with perceptual_weight > 0 the
         reconstruction objective is rec_weight * L1 + perceptual_weight * mean_b LPIPS(decoded_b, image_b)."""
         self.model = model
-        # stochastic depth (block.py:207-289): the student trunk's rate (the reference has one per objective -- clip_drop_rate,
-        # ssl_drop_rate, rec_drop_rate, vtp.py:205-207; the objectives share one trunk pass here, hence one rate and one draw per
-        # step) and the pixel decoder's drop_path_rate
+        # stochastic depth (block.py:207-289): the student trunk's rate per objective (clip_drop_rate / ssl_drop_rate / rec_drop_rate,
+        # vtp.py:205-207; `drop_rate` sets all three) and the pixel decoder's drop_path_rate.  The objectives are items of ONE list
+        # forward, each with its own rate and its own image subsets; rec and clip share an item only when they see the same tensor
+        # at the same rate (step(..., reconstruction_image=...))
         self.drop_rate, self.decoder_drop_rate = float(drop_rate), float(decoder_drop_rate)
+        self.clip_drop_rate = self.drop_rate if clip_drop_rate is None else float(clip_drop_rate)
+        self.ssl_drop_rate = self.drop_rate if ssl_drop_rate is None else float(ssl_drop_rate)
+        self.rec_drop_rate = self.drop_rate if rec_drop_rate is None else float(rec_drop_rate)
         self._drop_gen = torch.Generator().manual_seed(int(drop_seed))
         # SSL loss variants (DINOv2 conventions, SURVEY.md Appendix C): teacher-target centring "softmax" (EMA centre) or
         # "sinkhorn_knopp"; KoLeo regulariser on the student's global cls tokens (per view) with weight koleo_weight
@@ -296,6 +301,7 @@ class VTPTrainer:
         self.bucketer = GradBucketer(st.flat_g, group, shard=shard_optimizer, grad_dtype=BF if grad_dtype == "bf16" else F32,
                                      force=force_collectives)
         self.shard_optimizer = self.bucketer.shard
+        self._shard_layout = None  # bucket boundaries of the first sharded step (chunk ownership of the Adam moments)
         self.collectives = self.bucketer.active  # world > 1, or a one-rank group with force_collectives
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
         self._comm_events = []
@@ -407,10 +413,17 @@ class VTPTrainer:
             # masked-patch rows: the first n_masked of the Tm padded rows, n_masked read from device memory (graph-replay safe)
             ops.colsum_bf16_rows(t_logits[B2:], K, stats[K:], P["dev"]["n_masked_i"], Tm, K)
             stats[2 * K:2 * K + 1].copy_(P["dev"]["n_masked_f"])
+
+            def apply_centers():
+                ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
+                ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
             if self.collectives:
-                yield lambda: dist.all_reduce(stats, group=self.group)
-            ops.center_ema(self.center_dino, stats, 1.0 / (B2 * self.world), self.center_momentum, K)
-            ops.center_ema(self.center_ibot, stats[K:], 0.0, self.center_momentum, K, count=stats[2 * K:])
+                # the centres are next needed by the NEXT step's teacher softmax: the all-reduce is launched asynchronously on RCCL's
+                # stream, waited for together with the gradient buckets, and the EMA runs in the optimizer leg -- off the critical path
+                yield lambda: self.bucketer.works.append((dist.all_reduce(stats, group=self.group, async_op=True), None))
+                self._deferred.append(apply_centers)
+            else:
+                apply_centers()
         d_logits = ws.get("d_logits", (Ts, K), BF)
         ops.dino_ce(s_logits, probs, P["dev"]["t0"], P["dev"]["t1"], P["dev"]["w"], 1.0 / self.student_temp, self.ssl_loss_sum,
                     d_logits, Ts, K)
@@ -503,29 +516,41 @@ class VTPTrainer:
         masks_dev = up.pop("masks")
         return dict(**{"global": global_crops, "local": local_crops}, masks=masks_dev, plan=plan, dev=up)
 
-    def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
+    def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None, rec_images=None):
         """_step_body plus the bookkeeping of which flat ranges have been handed to the gradient exchange so far (known at
         generator time, i.e. also while the body is being captured into hipGraph segments and no collective runs)."""
         self._reduced_ranges = []
-        for ev in self._step_body(images, text, ssl):
+        for ev in self._step_body(images, text, ssl, rec_images):
             if not callable(ev):
                 self._reduced_ranges += merge_ranges([r for k in ev if k != "FINAL" for r in self._bucket_plan[k]])
             yield ev
 
-    def _step_body(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
+    def _separate_rec(self, images, text, rec_images) -> bool:
+        """does the reconstruction objective need its own trunk item?  (another tensor than the clip objective's, or another
+        stochastic-depth rate -- vtp.py:323-338 takes `image` and `reconstruction_image`, with a drop rate per objective)"""
+        return text is not None and (rec_images is not None and rec_images is not images or self.clip_drop_rate != self.rec_drop_rate)
+
+    def _step_body(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None, rec_images=None):
         st = self.store
         dist = self.bucketer.dist
-        B, _, H, W = images.shape
+        sep = self._separate_rec(images, text, rec_images)
+        rec_img = images if rec_images is None else rec_images
+        leads = [images, rec_img] if sep else [rec_img]   # list items in front of the SSL crops: [clip | rec] or the shared one
+        rec_seg = 1 if sep else 0
+        Bc, Nc = images.shape[0], (images.shape[2] // 16) * (images.shape[3] // 16) + 1   # the clip item (= item 0)
+        B, _, H, W = rec_img.shape
         h, w = H // 16, W // 16
         N = h * w + 1
         st.zero_grad()
         self.loss_sum.zero_()
         self.clip_loss_sum.zero_()
-        if ssl is not None:  # one student list forward: [images | masked global crops | local crops]
+        self._deferred = []  # work that only has to be done by the end of the step (runs in the optimizer leg, behind every collective)
+        if ssl is not None:  # one student list forward: [clip images | rec images | masked global crops | local crops]
             self.ssl_loss_sum.zero_()
-            xnf = (yield from self._ssl_gen(ssl, lead_images=images))["xnf"][:B * N]  # rows of the lead item
+            xnf_all = (yield from self._ssl_gen(ssl, lead_images=leads))["xnf"]
         else:
-            xnf = self.trunk.forward(images, train=True)
+            xnf_all = self.trunk.forward_list([(im, None) for im in leads], train=True)
+        xnf = xnf_all[:Bc * Nc]  # rows of the clip item (item 0; the shared item when rec and clip see the same pass)
         # the text tower's GEMMs are small (M = 77 B rows): it is issued on its own stream (with its own wgrad side stream,
         # OVERLAP lane 1) so that it runs concurrently with the decoder forward / the first decoder-backward blocks
         par_text = text is not None and OVERLAP.enabled and os.environ.get("VTP_TEXT_STREAM", "1") != "0"
@@ -539,63 +564,67 @@ class VTPTrainer:
             T.wait_stream(main)
             with torch.cuda.stream(T), OVERLAP.lane(1):
                 f_txt = self.text.forward(text, train=True)
-        lat = self.trunk.latents()
+        lat = self.trunk.latents(seg=rec_seg)
         t = self.decoder.forward(lat, B, h, w, train=True)
         dt = self.decoder._ctx[0].get("b.dt", (B * h * w, 768), BF)
-        ops.l1_loss_fwd_bwd(t, images, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
+        ops.l1_loss_fwd_bwd(t, rec_img, dt, self.loss_sum, B, h, w, self.rec_weight / (B * 3 * H * W))
         if self.perceptual_weight > 0:  # perceptual term: adds its gradient w.r.t. the decoder output into dt
-            self.lpips_val = self.lpips.loss_and_grad(t, images, dt, self.perceptual_weight, B, H, W)
+            self.lpips_val = self.lpips.loss_and_grad(t, rec_img, dt, self.perceptual_weight, B, H, W)
         held = None  # bucket keys whose gradients are being produced on the text stream
         if text is not None:
-            d_xnf = self.trunk.d_xnf_buffer()[:B * N]  # rows of the lead item
+            d_xnf = self.trunk.d_xnf_buffer()[:Bc * Nc]  # rows of the clip item
             cw = self.clip.ws
             Dt = self.clip.Dt
-            f_img = self.clip.image_features(xnf, B, N)
+            f_img = self.clip.image_features(xnf, Bc, Nc)
             img_n, inv_i = self.clip.normalize(f_img, "img")
             if par_fwd:
                 main.wait_stream(T)
             else:
                 f_txt = self.text.forward(text, train=True)
             txt_n, inv_t = self.clip.normalize(f_txt, "txt")
-            Bg = B * self.world
+            Bg = Bc * self.world
             if self.collectives:
                 img_all = cw.get("img_all", (Bg, Dt), F32)
                 txt_all = cw.get("txt_all", (Bg, Dt), F32)
 
                 def gather():
-                    self._all_gather_rows(img_all, img_n)
-                    self._all_gather_rows(txt_all, txt_n)
+                    works = [self._all_gather_rows(img_all, img_n, async_op=True), self._all_gather_rows(txt_all, txt_n, async_op=True)]
+                    for wk in works:
+                        if wk is not None:
+                            wk.wait()
                 yield gather
             else:
                 img_all, txt_all = img_n, txt_n
-            d_img_l = cw.get("d_img_l", (B, Dt), F32)
-            d_txt_l = cw.get("d_txt_l", (B, Dt), F32)
+            d_img_l = cw.get("d_img_l", (Bc, Dt), F32)
+            d_txt_l = cw.get("d_txt_l", (Bc, Dt), F32)
             d_img_all = cw.get("d_img_all", (Bg, Dt), F32)
             d_txt_all = cw.get("d_txt_all", (Bg, Dt), F32)
-            scratch = cw.get("logits", (2 * B * Bg,), F32)
+            scratch = cw.get("logits", (2 * Bc * Bg,), F32)
             if st.has("logit_bias"):
                 # SigLIP (logit_bias present, vtp.py:185-188): every (local image, any text) pair once across the ranks; the text
                 # side gets its gradient through the gathered columns only
-                ops.siglip_loss(img_n, txt_all, st.p("logit_scale"), st.p("logit_bias"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
+                ops.siglip_loss(img_n, txt_all, st.p("logit_scale"), st.p("logit_bias"), Bc, Bg, Dt, self.rank * Bc, self.clip_loss_sum,
                                 d_img_l, d_txt_all, st.g("logit_scale"), st.g("logit_bias"), scratch)
                 d_txt_l.zero_()
                 d_img_all.zero_()
             else:
-                ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), B, Bg, Dt, self.rank * B, self.clip_loss_sum,
+                ops.clip_loss(img_n, txt_n, img_all, txt_all, st.p("logit_scale"), Bc, Bg, Dt, self.rank * Bc, self.clip_loss_sum,
                               d_img_l, d_txt_l, d_img_all, d_txt_all, st.g("logit_scale"), scratch)
             if self.collectives:
-                rs_i = cw.get("rs_i", (B, Dt), F32)
-                rs_t = cw.get("rs_t", (B, Dt), F32)
+                rs_i = cw.get("rs_i", (Bc, Dt), F32)
+                rs_t = cw.get("rs_t", (Bc, Dt), F32)
 
                 def scatter():
-                    self._reduce_scatter_rows(rs_i, d_img_all)
-                    self._reduce_scatter_rows(rs_t, d_txt_all)
+                    works = [self._reduce_scatter_rows(rs_i, d_img_all, async_op=True), self._reduce_scatter_rows(rs_t, d_txt_all, async_op=True)]
+                    for wk in works:
+                        if wk is not None:
+                            wk.wait()
                 yield scatter
             else:
                 rs_i, rs_t = d_img_all, d_txt_all
             # total feature gradient = local-loss term + the terms every rank's loss contributes to these rows
-            ops.reduce_slabs(rs_i, B * Dt, 1, d_img_l, B * Dt, accumulate=True)
-            ops.reduce_slabs(rs_t, B * Dt, 1, d_txt_l, B * Dt, accumulate=True)
+            ops.reduce_slabs(rs_i, Bc * Dt, 1, d_img_l, Bc * Dt, accumulate=True)
+            ops.reduce_slabs(rs_t, Bc * Dt, 1, d_txt_l, Bc * Dt, accumulate=True)
             if self.clip_weight != 1.0:
                 d_img_l.mul_(self.clip_weight)
                 d_txt_l.mul_(self.clip_weight)
@@ -620,7 +649,7 @@ class VTPTrainer:
                 yield from self._tower_backward("text", self.text.backward(d_f_txt), self.text.depth)
                 yield ["text_head"]
             d_f_img = self.clip.normalize_bwd(d_img_l, img_n, inv_i, "img")
-            self.clip.image_backward(d_f_img, xnf, d_xnf, B, N)  # writes the cls rows of d_xnf
+            self.clip.image_backward(d_f_img, xnf, d_xnf, Bc, Nc)  # writes the cls rows of the clip item in d_xnf
             OVERLAP.join()
             if held is not None:
                 held.append("clip_head")
@@ -652,8 +681,10 @@ class VTPTrainer:
             # no head writes the cls rows of d_xnf on this step: clear what an earlier step with another objective set left there
             # (the workspace is keyed by shape, not by objectives)
             self.trunk.d_xnf_buffer().zero_()
-        yield from self._tower_backward("trunk", self.trunk.backward(d_lat), self.trunk.depth)
+        yield from self._tower_backward("trunk", self.trunk.backward(d_lat, lat_seg=rec_seg), self.trunk.depth)
         yield ["trunk_head", "FINAL"]
+        for fn in self._deferred:
+            fn()
         # ---- optimizer (after every bucket has been reduced)
         ranges = merge_ranges(list(self.ranges_all if text is not None else self.ranges_rec) + (self.ranges_ssl if ssl is not None else []))
         if self.shard_optimizer:
@@ -687,20 +718,22 @@ class VTPTrainer:
     def _native_collectives(self) -> bool:
         return self.bucketer.dist.get_backend(self.group) == "nccl"
 
-    def _all_gather_rows(self, out: torch.Tensor, inp: torch.Tensor):
+    def _all_gather_rows(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """async_op (RCCL only): returns the work handle; the caller waits where the data is consumed, so that independent
+        collectives (image and text features) are in flight together instead of one stream-blocking call after the other"""
         dist = self.bucketer.dist
         if self._native_collectives():
-            dist.all_gather_into_tensor(out, inp, group=self.group)
+            return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
         else:
             B = inp.shape[0]
             out.zero_()
             out[self.rank * B:(self.rank + 1) * B].copy_(inp)
             dist.all_reduce(out, group=self.group)
 
-    def _reduce_scatter_rows(self, out: torch.Tensor, inp: torch.Tensor):
+    def _reduce_scatter_rows(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         dist = self.bucketer.dist
         if self._native_collectives():
-            dist.reduce_scatter_tensor(out, inp, group=self.group)
+            return dist.reduce_scatter_tensor(out, inp, group=self.group, async_op=async_op)
         else:
             B = out.shape[0]
             tmp = inp.clone()
@@ -709,11 +742,20 @@ class VTPTrainer:
 
     def _shard_recs(self, opt_ranges):
         """The buckets reduce-scattered during this step; together they must cover exactly what the optimizer updates."""
-        recs = [self.bucketer._rec(lo, hi) for lo, hi in self._reduced_ranges]
         got = merge_ranges(self._reduced_ranges)
         if got != list(opt_ranges):
             raise RuntimeError(f"sharded optimizer: reduced gradient ranges {got} differ from the optimizer's ranges {list(opt_ranges)}")
-        return recs
+        # Adam moments live on the rank that owns a chunk, and ownership follows the bucket boundaries: the layout must be the
+        # same on every step (a step with another objective set would merge other buckets and hand chunks -- with stale moments --
+        # to other owners)
+        layout = tuple(self._reduced_ranges)
+        if self._shard_layout is None:
+            self._shard_layout = layout
+        elif layout != self._shard_layout:
+            raise RuntimeError("sharded optimizer: the gradient-bucket layout changed between steps (another set of objectives?); the "
+                               "rank-sharded Adam moments are tied to the first step's layout -- use one objective set per trainer, "
+                               "or shard_optimizer=False")
+        return [self.bucketer._rec(lo, hi) for lo, hi in self._reduced_ranges]
 
     def _timed(self, fn):
         """run a point where the main stream has to wait for RCCL; with time_comm the wait is bracketed by HIP events"""
@@ -782,28 +824,34 @@ class VTPTrainer:
         if final:
             self._timed(self.bucketer.wait)  # the generator's next (last) leg is the optimizer
 
-    def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None, ssl: Optional[dict] = None):
+    def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None, ssl: Optional[dict] = None,
+             reconstruction_image: Optional[torch.Tensor] = None):
         """One optimizer step.  images: f32 [B,3,H,W]; text: int64 [B, context_length] or None; ssl: prepare_ssl(...)
-        output or None.  Objectives: rec (always) + clip (if text) + DINO/iBOT (if ssl; model must be vtp_amd.VTP).
-        Returns (rec_loss, clip_loss) as device scalar tensors (local to this rank; no host sync); the SSL loss is in
-        self.ssl_loss_sum."""
+        output or None; reconstruction_image: the reconstruction objective's own input (the reference's forward takes `image` and
+        `reconstruction_image`, vtp.py:323-338) -- None or the same tensor as `images`: rec and clip share one trunk item (identical
+        activations when their drop rates agree); another tensor (or clip_drop_rate != rec_drop_rate): each objective gets its own
+        item of the list forward, i.e. the reference's separate passes.  Objectives: rec (always) + clip (if text) + DINO/iBOT (if
+        ssl; model must be vtp_amd.VTP).  Returns (rec_loss, clip_loss) as device scalar tensors (local to this rank; no host
+        sync); the SSL loss is in self.ssl_loss_sum."""
         if ssl is not None and self.ssl_head is None:
             raise RuntimeError("SSL needs a vtp_amd.VTP model (DINO head + EMA teacher)")
         if text is not None and self.text is None:
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
         if text is not None and self._clip_unsupported:
             raise NotImplementedError(self._clip_unsupported)
+        same = reconstruction_image is None or reconstruction_image is images
         images = self.model._img(images)  # shape / device / dtype / layout settled at the boundary (raw pointers below)
+        rec_images = None if same else self.model._img(reconstruction_image)
         if text is not None:
             text = self.model._ids(text, check_range=False)
-        B, _, H, W = images.shape
+        B, _, H, W = (images if rec_images is None else rec_images).shape
         self._set_hyper()
-        self._draw_drop_plans(B, ssl)
+        self._draw_drop_plans(images, text, ssl, rec_images)
         try:
             if self.use_graphs:
-                self._step_graphs(images, text, ssl)
+                self._step_graphs(images, text, ssl, rec_images)
             else:
-                for ev in self._step_gen(images, text, ssl):
+                for ev in self._step_gen(images, text, ssl, rec_images):
                     self._handle(ev)
         finally:
             # the stochastic-depth plan belongs to THIS step: evaluation passes and the autograd path (get_intermediate_layers,
@@ -813,12 +861,20 @@ class VTPTrainer:
         self.model._pver = self.model._param_version()
         return self.loss_sum / float(B * 3 * H * W), self.clip_loss_sum
 
-    def _draw_drop_plans(self, B: int, ssl):
-        """fresh image subsets for every block / branch of this step (host randperm -> static device index buffers)"""
-        for rate, eng, batches in ((self.drop_rate, self.trunk, [B] + ([ssl["global"].shape[0], ssl["local"].shape[0]] if ssl else [])),
-                                   (self.decoder_drop_rate, self.decoder, [B])):
-            if rate > 0:
-                plan = eng.stack.make_drop_plan([(b, 0, None) for b in batches], rate, self._drop_gen, self.world, self.rank)
+    def _draw_drop_plans(self, images, text, ssl, rec_images):
+        """fresh image subsets for every block / branch of this step (host randperm -> static device index buffers); one rate per
+        list item: [clip | rec] or the shared lead item, then the SSL crops"""
+        rec_b = (images if rec_images is None else rec_images).shape[0]
+        if self._separate_rec(images, text, rec_images):
+            items, rates = [images.shape[0], rec_b], [self.clip_drop_rate, self.rec_drop_rate]
+        else:
+            items, rates = [rec_b], [self.rec_drop_rate]
+        if ssl:
+            items += [ssl["global"].shape[0], ssl["local"].shape[0]]
+            rates += [self.ssl_drop_rate, self.ssl_drop_rate]
+        for rts, eng, batches in ((rates, self.trunk, items), ([self.decoder_drop_rate], self.decoder, [rec_b])):
+            if max(rts) > 0:
+                plan = eng.stack.make_drop_plan([(b, 0, None) for b in batches], rts, self._drop_gen, self.world, self.rank)
                 eng.stack.set_drop_plan(plan)
             else:
                 eng.stack.set_drop_plan(None)
@@ -829,7 +885,9 @@ class VTPTrainer:
     # ---- training-state checkpoint: the model's own state_dict (student, teacher, heads) travels in the
     # reference's HF layout; this is the rest of the state a resumed run needs
     def state_dict(self) -> dict:
-        """Optimizer moments (as name -> tensor, the same keys as model.state_dict()), step counter and SSL centres."""
+        """Optimizer moments (as name -> tensor, the same keys as model.state_dict()), step counter and SSL centres.
+        With shard_optimizer the moments are gathered from their owners: this is a COLLECTIVE call -- every rank must make it
+        (`if rank == 0: trainer.state_dict()` would hang); save from rank 0 afterwards."""
         st = self.store
         sd = {"step": self.step_no, "exp_avg": {}, "exp_avg_sq": {}}
         m, v = self._gather_moments()
@@ -855,7 +913,7 @@ class VTPTrainer:
         self.sync_replicas()
 
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
-    def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None):
+    def _step_graphs(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None, rec_images=None):
         skey = None
         if ssl is not None:
             pl = ssl["plan"]
@@ -864,11 +922,13 @@ class VTPTrainer:
         # values; lr / betas / weight decay / teacher temperature / EMA momentum live in device memory and are not part of the key
         baked = (self.clip_weight, self.rec_weight, self.perceptual_weight, self.student_temp, self.koleo_weight, self.centering,
                  self.teacher_temp if self.centering == "sinkhorn_knopp" else None, self.center_momentum)
-        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, self.drop_rate, self.decoder_drop_rate, baked)
+        key = (tuple(images.shape), None if text is None else tuple(text.shape), skey, None if rec_images is None else tuple(rec_images.shape),
+               self.clip_drop_rate, self.ssl_drop_rate, self.rec_drop_rate, self.decoder_drop_rate, baked)
         plan = self._graphs.get(key)
         if plan is None:
             st = self.store
             static_img = images.clone()
+            static_rec = None if rec_images is None else rec_images.clone()
             static_txt = None if text is None else text.clone()
             static_ssl = None
             if ssl is not None:  # static copies of every per-step SSL input (crops, masks, index tensors)
@@ -882,7 +942,7 @@ class VTPTrainer:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for ev in self._step_gen(static_img, static_txt, static_ssl):
+                for ev in self._step_gen(static_img, static_txt, static_ssl, static_rec):
                     self._handle(ev)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
@@ -897,7 +957,7 @@ class VTPTrainer:
             del snap
             segs = []
             pool = torch.cuda.graph_pool_handle()
-            gen = self._step_gen(static_img, static_txt, static_ssl)
+            gen = self._step_gen(static_img, static_txt, static_ssl, static_rec)
             done = False
             while not done:
                 g = torch.cuda.CUDAGraph()
@@ -909,10 +969,12 @@ class VTPTrainer:
                     except StopIteration:
                         done = True
                 segs.append((g, ev))
-            plan = (static_img, static_txt, static_ssl, segs)
+            plan = (static_img, static_txt, static_ssl, segs, static_rec)
             self._graphs[key] = plan
-        static_img, static_txt, static_ssl, segs = plan
+        static_img, static_txt, static_ssl, segs, static_rec = plan
         static_img.copy_(images)
+        if rec_images is not None:
+            static_rec.copy_(rec_images)
         if text is not None:
             static_txt.copy_(text)
         if ssl is not None:

@@ -287,7 +287,9 @@ def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_pla
     else:
         t_logits = teacher()
     # ---- student: masked global crops + local crops through the SAME trunk weights (vtp.py:452-484)
-    items = ([(lead_images, None)] if lead_images is not None else []) + [(global_crops, masks_u8), (local_crops, None)]
+    # lead_images: one tensor, or a list of tensors (separate clip / reconstruction inputs, vtp.py:323-338): one list item each
+    leads = [] if lead_images is None else (list(lead_images) if isinstance(lead_images, (list, tuple)) else [lead_images])
+    items = [(im, None) for im in leads] + [(global_crops, masks_u8), (local_crops, None)]
     xnf = model._trunk.forward_list(items, train=train, tag="ssl")
     ctx = model._trunk.ctx()
     seg_g, seg_l = ctx.segs[-2], ctx.segs[-1]
