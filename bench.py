@@ -462,8 +462,19 @@ def main():
         e1.record()
         recs.append((2.0 * M * H * K, e0, e1, ("gemm_dgrad_swiglu", M, H, K, 0, 1)))
 
+    orig_grp = ops.WgradGroup.launch
+
+    def timed_grp(self):  # the block's grouped weight-gradient launch: sum of 2 N K tokens over its problems
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_grp(self)
+        e1.record()
+        fl = sum(2.0 * r[7] * r[8] * self.Ktok for r in self.rows)
+        recs.append((fl, e0, e1, ("gemm_tn_grouped", len(self.rows), self.ntiles, self.Ktok, 1, self.splits)))
+
     if rank == 0:
         ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = timed(orig_nt), timed(orig_tn), timed_qkv, timed_dsw
+        ops.WgradGroup.launch = timed_grp
     trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
     overlap_was = eng.OVERLAP.enabled
     eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
@@ -472,6 +483,7 @@ def main():
         torch.cuda.synchronize()
     finally:
         ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = orig_nt, orig_tn, orig_qkv, orig_dsw
+        ops.WgradGroup.launch = orig_grp
         eng.OVERLAP.enabled = overlap_was
     if rank == 0:
         fl = sum(r[0] for r in recs)
@@ -503,7 +515,7 @@ def main():
                 traffic, traffic_src = round(by / n), f"profiles/{os.path.basename(pmc)} (separate --pmc passes; bytes per launch)"
             except (KeyError, ValueError):
                 pass
-        roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad + TN wgrad, 256x256 8-phase and ring tile configs, all epilogues)",
+        roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm8p_grouped_tn_kernel + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad, TN wgrad incl. the per-block grouped launches, 256x256 8-phase and ring tile configs, all epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
                 "avg_launch_us": round(ms * 1e3 / len(recs), 2), "gemm_ms_per_step": round(ms, 3),

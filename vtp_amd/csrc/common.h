@@ -61,8 +61,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // 2^x as ONE v_exp_f32 (exp2f() adds a denormal-range fix-up: 6 VALU instead of 1); results below 2^-126 flush to 0, which is
 // what a softmax numerator wants
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// sigmoid / SiLU with ONE v_rcp_f32 instead of an IEEE division (v_div_scale x2, v_rcp, 3 fma, v_div_fmas, v_div_fixup: 9
+// instructions per element -- a third of the SwiGLU epilogue's VALU work).  v_rcp_f32 is accurate to 1 ulp; every caller rounds
+// the result to bf16 next, so the value changes only within ~1.5 fp32 ulp of a bf16 rounding boundary (about 2e-5 of the elements,
+// by one bf16 ulp -- inside the per-kernel parity bar, tests/test_kernels_gpu.py).
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

@@ -337,9 +337,14 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   seg_barrier();
 
   int ktg = 0;  // k-tiles computed so far (across my tiles): ring half = ktg & 1
+  unsigned long long cyc0 = 0;
   auto stamp = [&](int ti, int which) {
-    if (__builtin_expect(p.timing != nullptr, 0) && tid == 0 && ti < 16)
+    if (__builtin_expect(p.timing != nullptr, 0) && tid == 0 && ti < 16) {
       p.timing[((size_t)blockIdx.x * 16 + ti) * 4 + which] = wall_clock64();
+      // slot 3: shader cycles (s_memtime) the k loop took -- with the 100 MHz stamps this gives the clock the CU ran at
+      if (which == 0) cyc0 = clock64();
+      if (which == 1) p.timing[((size_t)blockIdx.x * 16 + ti) * 4 + 3] = clock64() - cyc0;
+    }
   };
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
@@ -348,6 +353,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
     if constexpr (TRANS) do_csum = p.colsum != nullptr && wc == 0 && n0 == 0;
     if (wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
     for (int kt = 0; kt < nk; ++kt, ++ktg) {
+      if (__builtin_expect(p.timing != nullptr, 0) && tid == 0 && ti == 1 && kt < 16)  // diagnostics: start of every k-tile of tile 1
+        p.timing[(size_t)(gridDim.x + blockIdx.x) * 64 + kt] = wall_clock64();
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       Frags b1, b2, a1[2], a2[2];
       // ---- phase 0: B-first + A-first -> quadrant (cols 0..31, rows 0..63)
