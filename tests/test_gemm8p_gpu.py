@@ -229,3 +229,35 @@ def test_grouped_wgrad_matches_torch(Ktok, D, H):
     g1.ticket = torch.zeros(max(g1.ntiles, 256), dtype=torch.int32, device=DEV)
     g1.launch()
     check(out.view(D, H), dy.float().T @ hid.float(), "grouped dW overwrite", bf16_out=False, scale=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,epi_name", [(8192, 768, 4096, "bf16"), (8100, 1024, 4096, "f32"), (4000, 1024, 4160, "gelu"),
+                                            (12288, 512, 8192, "bf16")])
+def test_in_launch_split_k_combine(M, N, K, epi_name):
+    """few-tile / long-K shapes (text tower, pixel-decoder dgrads, DINO head): the 256 x 256 kernel cuts K into slices and the
+    last-arriving slice of a tile combines them and runs the epilogue (heuristic path, no forced configuration); repeated launches
+    must agree (tickets return to zero)"""
+    from vtp_amd import _lib
+    o = ops()
+    _lib.load().vtp_set_gemm_tuning(-1, 3)  # the module fixture forces cfg 8 with no K split: back to the dispatcher's choice
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, device=DEV, generator=g))
+    w = bf(torch.randn(N, K, device=DEV, generator=g) * 0.05)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().T + bias
+    for rep in range(3):
+        if epi_name == "f32":
+            x0 = torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+            out = torch.full((M, N), float("nan"), device=DEV)
+            o.gemm_nt(a, w, out, bias=bias, resid=x0, epi=o.EPI_F32)
+            check(out, ref + x0, f"combine f32 {M}x{N}x{K}", bf16_out=False, scale=2e-5)
+        elif epi_name == "bf16":
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            o.gemm_nt(a, w, out, bias=bias, epi=o.EPI_BF16)
+            check(out, ref, f"combine bf16 {M}x{N}x{K}")
+        else:
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            o.gemm_nt(a, w, out, c2=pre, bias=bias, epi=o.EPI_GELU)
+            check(pre, ref, f"combine gelu pre {M}x{N}x{K}")
+            check(out, F.gelu(bf(ref).float()), f"combine gelu {M}x{N}x{K}", scale=4e-3)

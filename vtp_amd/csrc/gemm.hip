@@ -426,6 +426,16 @@ static bool use_8p_tn(int M, int N, int K, int splits, const GemmArgs& a) {
   return wgs >= 160 && wgs <= 256 && K / splits >= 1024;
 }
 
+// split factor of the in-launch K combine (1 = off).  Measured per shape in the step (gpurun_out/gemm_table_c*.txt): the publish +
+// combine costs ~30 us per launch, so it pays only where it halves a LONG k loop on a half-empty chip -- the pixel decoder's w12
+// dgrad (M = 8192, N = 768, K = 4096: 118.7 -> 81.7 us); with K <= 3072 or more than two slices every shape got slower
+static int combine_splits(int M, int N, int K) {
+  static const int on = getenv("VTP_GEMM_COMBINE") ? atoi(getenv("VTP_GEMM_COMBINE")) : 1;  // 0: A/B runs
+  if (!on || N < 256 || M < 1024 || K < 4096) return 1;
+  const int tiles = cdiv(M, 256) * cdiv(N, 256);
+  return (tiles >= 48 && tiles <= 128) ? 2 : 1;
+}
+
 // measured on MI355X at the VTP-B train-step shapes (tools/gemm_bench.py, profiles/gemm_bench_r01.log)
 static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (g_force_cfg >= 0) return g_force_cfg;
@@ -527,14 +537,24 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
   hipStream_t s = (hipStream_t)stream;
-  const int cfg = pick_cfg(M, N, K, epilogue, splits);
+  int cfg = pick_cfg(M, N, K, epilogue, splits);
+  // few output tiles, long K (the pixel decoder's and the text tower's dgrads, their K = 2048 .. 4096 projections): the 256 x 256
+  // kernel with the K range cut into slices that are combined INSIDE the launch by the last-arriving slice (which then runs the
+  // normal epilogue) -- tiles x slices fills the CUs that 30 .. 100 tiles alone leave idle
+  int cs = 1;
+  if (splits == 1 && g_force_cfg < 0 && epilogue <= VTP_EPI_GELU && gemm8p_fits(a, false)) cs = combine_splits(M, N, K);
+  if (cs > 1) {
+    a.k_split = ((K + cs - 1) / cs + 63) / 64 * 64;
+    cs = (K + a.k_split - 1) / a.k_split;
+    cfg = 8;
+  }
   switch (epilogue) {
-    case VTP_EPI_BF16: return launch_gemm<EPI_BF16, false>(a, 1, cfg, s);
-    case VTP_EPI_F32: return launch_gemm<EPI_F32, false>(a, 1, cfg, s);
+    case VTP_EPI_BF16: return launch_gemm<EPI_BF16, false>(a, cs, cfg, s);
+    case VTP_EPI_F32: return launch_gemm<EPI_F32, false>(a, cs, cfg, s);
     case VTP_EPI_SWIGLU:
       VTP_REQUIRE(N % 16 == 0 && bias, "vtp_gemm_nt: SwiGLU epilogue needs interleaved N %% 16 == 0 and a bias");
-      return launch_gemm<EPI_SWIGLU, false>(a, 1, cfg, s);
-    case VTP_EPI_GELU: return launch_gemm<EPI_GELU, false>(a, 1, cfg, s);
+      return launch_gemm<EPI_SWIGLU, false>(a, cs, cfg, s);
+    case VTP_EPI_GELU: return launch_gemm<EPI_GELU, false>(a, cs, cfg, s);
     case VTP_EPI_F32_ATOMIC: return launch_gemm<EPI_F32_ATOMIC, false>(a, splits, cfg, s);
     case VTP_EPI_F32_SLAB: return launch_gemm<EPI_F32_SLAB, false>(a, splits, cfg, s);
     default: VTP_REQUIRE(false, "vtp_gemm_nt: unknown epilogue %d", epilogue);

@@ -25,7 +25,9 @@
 //   * dedicated 32 KiB epilogue staging (4 KiB per wave) beside the 128 KiB ring: 160 KiB = all of a CU's LDS, 1 workgroup / CU.
 #include "gemm_common.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 namespace vtp {
 
@@ -264,7 +266,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   };
 
   // TN: column sums of A (bias gradient) ride along -- the wc == 0 waves of the first tile column add up the A fragments they
-  // load anyway (v_dot2_f32_bf16 against ones: 4 VALU per fragment, in the shadow of the MFMAs), one atomic per row per tile
+  // load anyway (v_dot2_f32_bf16 against ones: 4 VALU per fragment, in the shadow of the MFMAs), one atomic per row per tile.
+  // (Spreading the sums over the four waves of a row group was measured slower: 556 vs 510 us for a trunk block's grouped launch.)
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   bool do_csum = false;
   auto add_csum = [&](const Frags (&fr)[2], int jbase) {
@@ -410,13 +413,18 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         }
       }
     }
-    if constexpr (EPI == EPI_F32 && TRANS) {
+    if constexpr (EPI != EPI_F32_SLAB && EPI != EPI_F32_ATOMIC) {
       if (gt.part != nullptr) {
         // split-K combine inside the launch (cdna_hip_programming.md, "In-launch split-K reduction"): every slice publishes its
-        // accumulators (plain 16-B stores, fragment-major: a lane re-reads exactly its own positions) -> every wave drains its
-        // stores -> barrier -> lane 0: agent-scope release, drain, ticket.  The slice that draws the last ticket acquires, adds the
-        // other slices' partials to its registers in slice order and runs the epilogue; nobody ever waits for another workgroup.
-        f32x4* mine = (f32x4*)gt.part + (((size_t)gt.tile * gt.splits + zslice) * 8 + wave) * 2048 + lane;
+        // accumulators (fragment-major: a lane re-reads exactly its own positions) -> every wave drains its stores -> barrier ->
+        // lane 0 takes a ticket.  The slice that draws the last ticket acquires, adds the other slices' partials to its registers
+        // in slice order and runs the epilogue; nobody ever waits for another workgroup.
+        // write-through (sc1) 16-B stores through a wave-uniform buffer descriptor: the partial sums leave the XCD's L2 as they
+        // are written, so no agent-scope release (an L2 write-back of everything dirty) is needed before the ticket
+        // (cdna_hip_programming.md, "publish-large": 3.0 vs 8.2 us per 64 KB workgroup; here 256 KB)
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+        const f32x4* mine = (const f32x4*)gt.part + (((size_t)gt.tile * gt.splits + zslice) * 8 + wave) * 2048;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, 2048 * 16, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -426,14 +434,12 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
               f32x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-              mine[((i * 4 + j) * 4 + q) * 64] = v;
+              __builtin_amdgcn_raw_buffer_store_b128((u32x4_t)v, rsrc, lane * 16 + ((i * 4 + j) * 4 + q) * 1024, 0, /*sc1*/ 16);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = (int*)(smem + P8_RING);  // the epilogue staging area is idle here (TN epilogues store directly)
+        int* flag = (int*)(smem + P8_RING);  // the epilogue staging area is idle here (the epilogue follows the combine)
         if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           const int t = __hip_atomic_fetch_add(gt.ticket + gt.tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int last = t == gt.splits - 1;
           if (last) {
@@ -488,7 +494,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     zslice = c / ntiles;
     bx = c - zslice * ntiles;
   }
-  gemm8p_body<EPI, TRANS, VAR, XMODE>(p, bx, zslice, flat ? ntiles : (int)gridDim.x, flat, GroupTile{nullptr, nullptr, 0, 1});
+  GroupTile gt{nullptr, nullptr, 0, 1};
+  if (flat && p.part != nullptr) gt = GroupTile{p.part, p.ticket, bx, (int)gridDim.x / ntiles};
+  gemm8p_body<EPI, TRANS, VAR, XMODE>(p, bx, zslice, flat ? ntiles : (int)gridDim.x, flat, gt);
 }
 
 // Grouped weight gradients: up to 8 problems C_g[M_g, N_g] (+)= A_g[K, M_g]^T B_g[K, N_g] over the SAME K token rows (the four linear
@@ -538,11 +546,52 @@ __global__ __launch_bounds__(512) void gemm8p_grouped_tn_kernel(const GroupArgs 
 static unsigned long long* g_p8_timing = nullptr;
 static int g_p8_grid = 0, g_p8_delay = 0;
 
+// scratch of the in-launch split-K combine: launches on one stream are serialised and may share a buffer, concurrent streams (the
+// text tower beside the decoder) must not.  A pool of 8 slots (256 tile-slices x 256 KiB + tickets each) is allocated at the FIRST
+// combine launch of the process -- an eager one: the trainers warm up eagerly before any stream capture, and allocating under
+// capture is not possible -- and every stream handle is bound to a slot the first time it is seen (no allocation then, so a
+// capture stream that shows up later is fine).
+struct CombineScratch {
+  float* part = nullptr;
+  int* ticket = nullptr;
+};
+static CombineScratch* combine_scratch(hipStream_t s) {
+  constexpr int SLOTS = 8;
+  static std::mutex mu;
+  static CombineScratch pool[SLOTS];
+  static std::unordered_map<hipStream_t, int> slot_of;
+  static bool ready = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ready) {
+    float* part = nullptr;
+    int* ticket = nullptr;
+    if (hipMalloc((void**)&part, (size_t)SLOTS * 256 * 65536 * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&ticket, (size_t)SLOTS * 1024 * sizeof(int)) != hipSuccess ||
+        hipMemset(ticket, 0, (size_t)SLOTS * 1024 * sizeof(int)) != hipSuccess) return nullptr;
+    for (int i = 0; i < SLOTS; ++i) pool[i] = CombineScratch{part + (size_t)i * 256 * 65536, ticket + i * 1024};
+    ready = true;
+  }
+  auto it = slot_of.find(s);
+  if (it == slot_of.end()) it = slot_of.emplace(s, (int)(slot_of.size() % SLOTS)).first;
+  return &pool[it->second];
+}
+
 template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
 static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
   GemmArgs a = a0;
   a.timing = g_p8_timing;
   a.dbg_delay = g_p8_delay;
+  if constexpr (EPI != EPI_F32_SLAB && EPI != EPI_F32_ATOMIC) {
+    if (splits > 1) {  // in-launch combine: tiles x splits <= 256 (the caller's policy)
+      CombineScratch* c = combine_scratch(s);
+      if (!c || cdiv(a.M, 256) * cdiv(a.N, 256) * splits > 256) {
+        set_error("gemm8p: split-K combine scratch unavailable or too many tile slices");
+        return VTP_ERR_ARG;
+      }
+      a.part = c->part;
+      a.ticket = c->ticket;
+    }
+  }
   auto kern = gemm8p_kernel<EPI, TRANS, VAR, XMODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -584,12 +633,12 @@ bool gemm8p_fits(const GemmArgs& a, bool trans) {
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s) {
   switch (epi) {
     case EPI_BF16:  // the fused extras of the LDS-staged store path are separate instantiations (gemm_epilogue XMODE)
-      if (a.rope_pos) return launch8p<EPI_BF16, false, 0, 1>(a, 1, s);
-      if (a.swiglu_pre) return launch8p<EPI_BF16, false, 0, 2>(a, 1, s);
-      return launch8p<EPI_BF16, false, 0, 0>(a, 1, s);
-    case EPI_F32: return launch8p<EPI_F32, false>(a, 1, s);
-    case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false>(a, 1, s);
-    case EPI_GELU: return launch8p<EPI_GELU, false>(a, 1, s);
+      if (a.rope_pos) return launch8p<EPI_BF16, false, 0, 1>(a, splits, s);
+      if (a.swiglu_pre) return launch8p<EPI_BF16, false, 0, 2>(a, splits, s);
+      return launch8p<EPI_BF16, false, 0, 0>(a, splits, s);
+    case EPI_F32: return launch8p<EPI_F32, false>(a, splits, s);
+    case EPI_SWIGLU: return launch8p<EPI_SWIGLU, false>(a, splits, s);
+    case EPI_GELU: return launch8p<EPI_GELU, false>(a, splits, s);
     case EPI_F32_ATOMIC: return launch8p<EPI_F32_ATOMIC, false>(a, splits, s);
     case EPI_F32_SLAB: return launch8p<EPI_F32_SLAB, false>(a, splits, s);
     default: set_error("gemm8p: unsupported epilogue %d", epi); return VTP_ERR_ARG;

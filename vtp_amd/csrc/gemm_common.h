@@ -44,6 +44,10 @@ struct GemmArgs {
   // null: plain epilogue.
   const bf16* swiglu_pre;
   int swiglu_ld;
+  // in-launch split-K combine of the 256 x 256 kernel (few-tile shapes with a long K): fp32 partial sums [tiles][splits] x 256 KiB and
+  // one arrival ticket per tile; null: off.  Set by the launcher (per-stream scratch), never by callers.
+  float* part;
+  int* ticket;
   // diagnostics (vtp_gemm_debug): per workgroup and tile, s_memrealtime stamps {tile start, k loop done, epilogue issued}; null = off
   unsigned long long* timing;
   int dbg_delay;  // diagnostics: > 0: every second workgroup (per XCD) starts this many 10-ns ticks late (lock-step experiments);
