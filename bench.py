@@ -108,11 +108,11 @@ def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
     return f / 1e9
 
 
-def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=14.0):
+def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=100.0):
     """The CPU oracle (kind "port": oracle/vtp_oracle.py is a PyTorch restatement of the reference, itself PyTorch) timed on
     the host cores on a bounded sample of the SAME workload: one full train step (fwd + every loss that ran on the GPU + autograd
-    bwd + AdamW) at a scaled-down batch, fp32 and under torch.autocast("cpu", bf16).  2 warm-up steps, then
-    up to 10 timed steps or `budget_s` seconds per precision, median step time."""
+    bwd + AdamW) at a scaled-down batch in fp32 (and, if the host-time budget allows, under torch.autocast("cpu", bf16); SURVEY.md
+    §8d): 2 warm-up + 5 timed steps, median step time."""
     from oracle import vtp_oracle as O
     import numpy as np
     from vtp_amd.data import collate_ssl_masks
@@ -151,33 +151,33 @@ def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=14.0):
         loss.backward()
         opt.step()
 
-    def timed(autocast):
+    def timed(autocast, n_warm, n_timed):
         import contextlib
         ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
         ts = []
-        t_all = time.perf_counter()
-        for i in range(12):
+        for i in range(n_warm + n_timed):
             t0 = time.perf_counter()
             with ctx():
                 step()
-            dt = time.perf_counter() - t0
             if i >= n_warm:
-                ts.append(dt)
-            if time.perf_counter() - t_all > budget_s and len(ts) >= 2:
-                break
+                ts.append(time.perf_counter() - t0)
         ts.sort()
         return ts[len(ts) // 2], len(ts)
 
-    n_warm = 1 if do_ssl else 2  # the full step takes ~15 s on the host: 1 warm-up + >= 2 timed steps per precision
-    t32, n32 = timed(False)
-    t16, n16 = timed(True)
+    # SURVEY.md §8d / VERDICT r2: 2 warm-up + 5 timed fp32 steps, median.  The bf16-autocast leg (the like-for-like precision) is
+    # timed only while the whole baseline stays inside `budget_s` seconds of host time: the fp32 figure is the reported `value`.
+    t_all = time.perf_counter()
+    t32, n32 = timed(False, 2, 5)
+    auto = None
+    if time.perf_counter() - t_all + 4 * t32 < budget_s:
+        t16, n16 = timed(True, 1, 3)
+        auto = {"value": round(B_cpu / t16, 3), "unit": "images/sec", "steps": n16,
+                "note": 'same step under torch.autocast("cpu", dtype=torch.bfloat16), 1 warm-up'}
     objs = "L1" + ("+CLIP" if clip else "") + ("+DINO/iBOT (K=%d prototypes, 2 global + 8 local crops/img, EMA-teacher fwd)" % K if do_ssl else "")
     return {"value": round(B_cpu / t32, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"median of {n32} fp32 train steps (fwd + {objs} loss + bwd + AdamW) of the same model at batch {B_cpu} "
-                      f"after {n_warm} warm-up step(s)",
-            "bf16_autocast": {"value": round(B_cpu / t16, 3), "unit": "images/sec", "steps": n16,
-                              "note": 'same step under torch.autocast("cpu", dtype=torch.bfloat16)'},
-            "ms_per_step_fp32": round(t32 * 1e3, 1), "threads": n_thr}
+                      f"after 2 warm-up steps",
+            "bf16_autocast": auto, "ms_per_step_fp32": round(t32 * 1e3, 1), "threads": n_thr}
 
 
 def bench_forward(args, world, rank, dev):
@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS) + sorted(FORWARD_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1, help="images per CPU-oracle step (the full step costs ~9 s per image on a 128-thread host)")
     ap.add_argument("--no-lpips-run", action="store_true", help="skip the second measurement with the perceptual term on")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
     ap.add_argument("--no-separate-run", action="store_true",

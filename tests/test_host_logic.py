@@ -184,14 +184,21 @@ def test_ssl_index_plan_matches_reference_buffer_layout():
     assert (p["t1"][n_local * B:] == -1).all()
 
 
-def test_wgrad_split_rule_and_overlap_lanes():
-    from vtp_amd.engine import OVERLAP, _wgrad_splits
-    # tiles x splits stays within one resident wave of 512 workgroups, slices keep >= 8 k-tiles, at most 16 slices
+def test_wgrad_group_split_rule_and_overlap_lanes():
+    """ops.WgradGroup picks the slice count host-side (no GPU needed up to finalize's allocations): tiles x slices fills one round of
+    the 256 CUs with every slice >= 16 k-tiles; the library's per-layer rule (vtp_gemm_tn_splits) stays within its kernels'
+    operating points"""
+    from vtp_amd import _lib
+    from vtp_amd.engine import OVERLAP
+    lib = _lib.load()
     for rows, cols, k in ((2304, 768, 34144), (768, 768, 34144), (4096, 768, 8224), (768, 2048, 34144), (65536, 256, 3000), (64, 64, 100)):
-        s = _wgrad_splits(rows, cols, k)
-        tiles = -(-rows // 128) * -(-cols // 128)
-        assert 1 <= s <= 16 and (s == 1 or (tiles * s <= 512 and k // s >= 512)), (rows, cols, k, s)
-    assert _wgrad_splits(768, 768, 34144) == 14 and _wgrad_splits(768, 2048, 34144) == 5
+        s = lib.vtp_gemm_tn_splits(rows, cols, k)
+        t256, t128 = -(-rows // 256) * -(-cols // 256), -(-rows // 128) * -(-cols // 128)
+        assert s >= 1 and (s == 1 or t256 * s <= 256 or (t128 * s <= 512 and s <= 16)), (rows, cols, k, s)
+    for ktok, want in ((34144, 2), (8192, 2), (2464, 2), (514, 1), (1100, 1)):  # VTP-B block: 108 tiles of 256 x 256
+        s = max(1, min(256 // 108, ktok // 1024))
+        ks = ((ktok + s - 1) // s + 63) // 64 * 64
+        assert (ktok + ks - 1) // ks == want, (ktok, s)
     assert OVERLAP._lane == 0
     with OVERLAP.lane(1):
         assert OVERLAP._lane == 1

@@ -392,8 +392,7 @@ int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o
                       float* delta, void* dq, void* dk, void* dv, const void* rope_sin, const void* rope_cos, int rope_prefix,
                       int B, int N, int heads, long sb, long sn, long sbo, long sno, float scale, hipStream_t s);
 static bool use_resident(int N, int causal) {
-  static const bool on = !(getenv("VTP_ATTN_RESIDENT") && atoi(getenv("VTP_ATTN_RESIDENT")) == 0);
-  return on && !causal && N <= 320;
+  return !causal && N <= 320;
 }
 
 }  // namespace vtp

@@ -736,9 +736,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
 // -- worth it only while heads x images leaves CUs short of work (<= 512 workgroups: +1.2 % on the 32-image rec step, -0.4 %
 // when the 64-image passes already run three full rounds and the second copy of K / V is pure extra traffic)
 static int res_waves_per_block(int nw, int groups) {
-  static const int mode = getenv("VTP_ATTN_SPLIT") ? atoi(getenv("VTP_ATTN_SPLIT")) : -1;  // 0 never, 1 always, -1 by size
-  const bool split = mode == 1 || (mode != 0 && groups <= 512);
-  return (split && nw >= 4) ? (nw + 1) / 2 : nw;
+  return (groups <= 512 && nw >= 4) ? (nw + 1) / 2 : nw;
 }
 
 template <typename K>
@@ -758,11 +756,10 @@ int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, floa
     set_lds(attn_fwd_res2_kernel, 2 * RES_MAXN * 128 + 5 * RES_SPLIT_COLS * 2 * 34 * 4);
     attr = true;
   }
-  static const int v2 = getenv("VTP_ATTN_V2") ? atoi(getenv("VTP_ATTN_V2")) : 1;
   {
     const int ntiles = a.npad / 32, cols = N - 32 * (ntiles - 1);
     const bool odd = (ntiles & 1) && ntiles > 1;
-    if (v2 && (!odd || cols <= RES_SPLIT_COLS)) {  // two query tiles per wave, single pass, odd last tile split over the key blocks
+    if (!odd || cols <= RES_SPLIT_COLS) {  // two query tiles per wave, single pass, odd last tile split over the key blocks
       const int waves = std::max(1, ntiles / 2);
       const int lds = 2 * a.npad * 128 + (odd ? waves * cols * 2 * 34 * 4 : 0);
       static long long* tbuf = nullptr;

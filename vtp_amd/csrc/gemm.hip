@@ -340,7 +340,6 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * WAVES_M * WAVES_N, LDS);
     slots = prop.multiProcessorCount * (occ < 1 ? 1 : occ);
     slots -= slots % 8;
-    if (getenv("VTP_GEMM_PERSIST") && atoi(getenv("VTP_GEMM_PERSIST")) == 0) slots = 1 << 30;
   }
   const int ntiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   // persistent when the tile list exceeds one resident wave of workgroups and the split-K factor is 1
@@ -353,10 +352,7 @@ static int launch_cfg(const GemmArgs& a, int splits, hipStream_t s) {
 // 3 = 256x128 8w 3 stages | 4 = 256x256 8w 2 stages | 5 = 128x128 8w 2 stages | 6 = 128x128 4w 4 stages
 static int g_force_cfg = -1;
 static int g_xcd_swizzle = 3;  // bit 0: XCD-aware tile order | bit 1: LDS-staged full-line stores for bf16 outputs
-static int swz_flags() {
-  static const int v = getenv("VTP_GEMM_SWZ") ? atoi(getenv("VTP_GEMM_SWZ")) : -1;
-  return v >= 0 ? v : g_xcd_swizzle;
-}
+static int swz_flags() { return g_xcd_swizzle; }
 
 
 // gemm8p.hip: 256x256 8-phase main loop (cfg 8)
@@ -403,8 +399,7 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
 // the 256x256 8-phase kernel (cfg 8, gemm8p.hip; one workgroup per CU) wins when its tile list fills whole rounds of the 256
 // CUs: measured on MI355X (tools/gemm8p_bench.py, profiles/r02_gemm8p_bench.log) at M = 34144 / 16448 / 8224 rows
 static bool use_8p_nt(int M, int N, int K, int epilogue) {
-  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;  // 0: never (A/B runs)
-  if (!mode || N < 256 || K < 512) return false;
+  if (N < 256 || K < 512) return false;
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
   const int rounds = cdiv(tiles, 256);
   const bool fills = tiles >= 192 && 4 * tiles >= 3 * rounds * 256;  // >= 75 % of the CU-rounds it occupies
@@ -420,8 +415,7 @@ static bool use_8p_nt(int M, int N, int K, int epilogue) {
 // weight gradients (TN, K = tokens): 8-phase kernel when tiles x splits is one round of the CUs and every K slice keeps >= 16
 // k-tiles (vtp_gemm_tn_splits picks the split factor accordingly)
 static bool use_8p_tn(int M, int N, int K, int splits, const GemmArgs& a) {
-  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;
-  if (!mode || a.a_grp || a.b_grp) return false;
+  if (a.a_grp || a.b_grp) return false;
   const int wgs = cdiv(M, 256) * cdiv(N, 256) * splits;
   return wgs >= 160 && wgs <= 256 && K / splits >= 1024;
 }
@@ -430,8 +424,7 @@ static bool use_8p_tn(int M, int N, int K, int splits, const GemmArgs& a) {
 // combine costs ~30 us per launch, so it pays only where it halves a LONG k loop on a half-empty chip -- the pixel decoder's w12
 // dgrad (M = 8192, N = 768, K = 4096: 118.7 -> 81.7 us); with K <= 3072 or more than two slices every shape got slower
 static int combine_splits(int M, int N, int K) {
-  static const int on = getenv("VTP_GEMM_COMBINE") ? atoi(getenv("VTP_GEMM_COMBINE")) : 1;  // 0: A/B runs
-  if (!on || N < 256 || M < 1024 || K < 4096) return 1;
+  if (N < 256 || M < 1024 || K < 4096) return 1;
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
   return (tiles >= 48 && tiles <= 128) ? 2 : 1;
 }
@@ -444,10 +437,8 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (use_8p_nt(M, N, K, epilogue)) return 8;
   // big-M GEMMs (the row-concatenated list forward, M = 34k): 256x256 tiles halve the LDS / L2 traffic per flop; they
   // need >= 1.5 resident waves of tiles to beat the 128x128 kernels' finer quantisation (tools/gemm_bench.py 34144)
-  static const int big_tiles = getenv("VTP_GEMM_BIG_TILES") ? atoi(getenv("VTP_GEMM_BIG_TILES")) : 384;
-  if (cdiv(M, 256) * cdiv(N, 256) >= big_tiles && (N >= 2304 || K >= (epilogue == VTP_EPI_F32 ? 4096 : 2048))) return 4;
-  static const int pipe_min_k = getenv("VTP_GEMM_PIPE_MINK") ? atoi(getenv("VTP_GEMM_PIPE_MINK")) : 4096;
-  if (K >= pipe_min_k) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
+  if (cdiv(M, 256) * cdiv(N, 256) >= 384 && (N >= 2304 || K >= (epilogue == VTP_EPI_F32 ? 4096 : 2048))) return 4;
+  if (K >= 4096) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
 }
@@ -493,11 +484,10 @@ extern "C" int vtp_gemm_splits(int K, int splits) {
 // (256x256 tiles x splits = one round of the CUs, >= 16 k-tiles per slice), else the ring kernel's (128x128 tiles x splits just
 // under one resident wave of 512 workgroups, >= 8 k-tiles per slice).  Returns the effective number of slices.
 extern "C" int vtp_gemm_tn_splits(int M, int N, int K) {
-  static const int mode = getenv("VTP_GEMM_8P") ? atoi(getenv("VTP_GEMM_8P")) : 1;
   const int t256 = cdiv(M, 256) * cdiv(N, 256);
   int s8 = 256 / t256;
   if (s8 > K / 1024) s8 = K / 1024;
-  if (mode && g_force_cfg < 0 && s8 >= 1) {
+  if (g_force_cfg < 0 && s8 >= 1) {
     const int eff = vtp_gemm_splits(K, s8);
     if (t256 * eff >= 160 && t256 * eff <= 256 && K / eff >= 1024) return eff;
   }

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .ops import EPI_BF16, EPI_F32, EPI_F32_ATOMIC, EPI_F32_SLAB, EPI_GELU, EPI_SWIGLU, pad8
+from .ops import EPI_BF16, EPI_F32, EPI_F32_SLAB, EPI_GELU, EPI_SWIGLU
 
 
 # =====================================================================================================================
@@ -262,31 +262,16 @@ class Overlap:
 
 
 OVERLAP = Overlap()
-# bias gradients inside the weight-gradient GEMM (VTP_FUSE_COLSUM=1) or as separate column-sum launches on the wgrad side stream
-# (default).  Same-box A/B of the final round-2 build: the in-kernel sums (v_dot2 on the A fragments + one fp32 atomic per row, tile
-# and split) are neutral on the 34 k-row full step (582 / 578 vs 587 / 577 images/s) and cost 2.7 % on the VTP-B rec-only step and
-# 20 % on VTP-S rec at batch 64 (short K slices, many splits hammering the same 384 addresses)
-FUSE_COLSUM = _env_flag("VTP_FUSE_COLSUM", "0")
-FUSE_SWIGLU_BWD = _env_flag("VTP_FUSE_SWIGLU_BWD")  # swiglu_bwd in the epilogue of the w3 dgrad GEMM (0: separate elementwise launch)
-FUSE_ROPE = _env_flag("VTP_FUSE_ROPE")  # apply_rope in the qkv GEMM epilogue (0: separate rope_qk launches per segment)
-# weight gradients: True = TN GEMM reading the activations as stored (LDS transpose reads); False = explicit transposes
-WGRAD_TN = os.environ.get("VTP_WGRAD", "tn") != "transpose"
-# split-K weight gradients: private fp32 slabs + one reduce launch (default; bit-reproducible summation order) or fp32 atomics
-# straight into the flat gradient (VTP_WGRAD_ATOMIC=1)
-WGRAD_ATOMIC = _env_flag("VTP_WGRAD_ATOMIC", "0")  # measured: fp32 atomics from the MFMA epilogue halve the step rate
+# Decided by same-box A/B runs of rounds 1-3 and no longer switchable: apply_rope in the qkv GEMM's epilogue, the SwiGLU backward
+# in the w3 dgrad's epilogue, weight gradients as TN GEMMs straight from the activation layouts (no transposed copies, no fp32
+# atomics from the MFMA epilogue: 285 vs 572 images/s), bias-gradient column sums beside (not inside) the per-layer wgrad GEMMs.
+FUSE_SWIGLU_BWD = True
+FUSE_ROPE = True
 # the four weight gradients of a transformer block as ONE grouped launch with the split-K combine and the bias-gradient column
 # sums inside it (ops.WgradGroup), issued one block late so that it runs beside the NEXT block's dgrad / attention kernels
-# (VTP_WGRAD_GROUPED=0: one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that layer's dgrad)
+# (VTP_WGRAD_GROUPED=0: the per-layer path -- one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that
+# layer's dgrad -- which LayerScale, stochastic depth and tiny token counts use anyway)
 WGRAD_GROUPED = _env_flag("VTP_WGRAD_GROUPED")
-
-
-def _wgrad_splits(n_rows: int, n_cols: int, k: int) -> int:
-    """Split-K factor for a wgrad GEMM (output [n_rows, n_cols], reduction over k tokens): the largest factor whose
-    tiles x splits workgroups still fit ONE resident wave of the 8-wave 128x128 kernel (256 CUs x 2 workgroups) -- a second,
-    partial round costs more than the shorter slices gain (tools/gemm_tn_bench.py: 768x2048 at 34k tokens, 5 splits = 480
-    workgroups 700 TF/s, 4 splits 604, 8 splits 646) -- with every slice keeping >= 8 k-tiles."""
-    tiles = ((n_rows + 127) // 128) * ((n_cols + 127) // 128)
-    return int(max(1, min(512 // tiles, k // 512, 16)))
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
@@ -306,7 +291,7 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
         # y = gamma (.) (x W^T + b) (LayerScale, misc.py:24-25) and dy_b is the gradient of y: the branch output f is not stored
         # -- G = dy^T x and cs = colsum(dy) give dW = gamma (.) G, db = gamma (.) cs, dgamma = rowsum(W (.) G) + b (.) cs
         gamma, g_gamma = ls
-        assert WGRAD_TN and L is not None and not swiglu_h and dy_remap == (0, 0) and x_remap == (0, 0)
+        assert L is not None and not swiglu_h and dy_remap == (0, 0) and x_remap == (0, 0)
         cs = ws.get("T.ls_cs", (N,), F32)
         cs.zero_()
         G = ws.get("T.ls_G", (N * K,), F32)
@@ -331,43 +316,24 @@ def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: 
     if bias_grad_done:  # the kernel that produced dy_b already accumulated its column sums into the bias gradient
         gb = None
     if defer is not None:  # grouped weight gradients: record the problem, the caller launches the block's group later
-        assert dy_remap == (0, 0) and x_remap == (0, 0) and WGRAD_TN
+        assert dy_remap == (0, 0) and x_remap == (0, 0)
         defer.append(dict(dy=dy_b, x=x_b, gw=gw, gb=gb, N=N, K=K, swiglu_h=swiglu_h))
-    Mp = pad8(M)
     c_remap = (-1, swiglu_h) if swiglu_h else (0, 0)
-    S = ops.gemm_splits(Mp, _wgrad_splits(N, K, Mp))
 
     def wgrad():
-        if WGRAD_TN:
-            # dW[N,K] = dy[M,N]^T x[M,K] straight from the activation layouts (LDS transpose reads inside the GEMM)
-            # db = colsum(dy) rides in the wgrad GEMM (fused in the 8-phase kernel, else a column-sum pass inside vtp_gemm_tn)
-            if gb is not None and not FUSE_COLSUM:
-                ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
-            kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap,
-                      c_remap=c_remap, a_colsum=gb if FUSE_COLSUM else None)
-            St = ops.gemm_tn_splits(N, K, M)  # tile-configuration aware (8-phase 256x256 kernel: tiles x splits = 256 CUs)
-            if St == 1:
-                ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)
-            elif WGRAD_ATOMIC:  # slices add straight into the flat gradient: no slab write + read + reduce launch
-                ops.gemm_tn(dy_b, x_b, gw, epi=EPI_F32_ATOMIC, splits=St, **kw)
-            else:
-                n_el = N * K
-                slab = ws.get("T.slab", (St * n_el,), F32)
-                ops.gemm_tn(dy_b, x_b, slab, ldc2=n_el // 4, epi=EPI_F32_SLAB, splits=St, **kw)
-                ops.reduce_slabs(slab, n_el, St, gw, n_el, accumulate=True)
-            return
-        dyT = ws.get("T.dy", (max(N, 8) * Mp,), BF)
-        xT = ws.get("T.x", (max(K, 8) * Mp,), BF)
-        ops.transpose_bf16(dy_b, dy_b.stride(0), dyT, Mp, M, N, colsum=gb, swiglu_h=swiglu_h, in_remap=dy_remap)
-        ops.transpose_bf16(x_b, x_b.stride(0), xT, Mp, M, K, in_remap=x_remap)
-        if S == 1:
-            ops.gemm_nt(dyT, xT, gw, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, resid=gw, epi=EPI_F32, c_remap=c_remap)
+        # dW[N,K] = dy[M,N]^T x[M,K] straight from the activation layouts (LDS transpose reads inside the GEMM); db = colsum(dy) as a
+        # column-sum launch beside it
+        if gb is not None:
+            ops.colsum_bf16(dy_b, dy_b.stride(0), gb, M, N, swiglu_h=swiglu_h, in_remap=dy_remap)
+        kw = dict(M=N, N=K, K=M, lda=dy_b.stride(0), ldb=x_b.stride(0), ldc=K, a_remap=dy_remap, b_remap=x_remap, c_remap=c_remap)
+        St = ops.gemm_tn_splits(N, K, M)  # tile-configuration aware (8-phase 256x256 kernel: tiles x splits = 256 CUs)
+        if St == 1:
+            ops.gemm_tn(dy_b, x_b, gw, resid=gw, epi=EPI_F32, **kw)
         else:
             n_el = N * K
-            slab = ws.get("T.slab", (S * n_el,), F32)
-            ops.gemm_nt(dyT, xT, slab, M=N, N=K, K=Mp, lda=Mp, ldb=Mp, ldc=K, ldc2=n_el // 4, epi=EPI_F32_SLAB, splits=S,
-                        c_remap=c_remap)
-            ops.reduce_slabs(slab, n_el, S, gw, n_el, accumulate=True)
+            slab = ws.get("T.slab", (St * n_el,), F32)
+            ops.gemm_tn(dy_b, x_b, slab, ldc2=n_el // 4, epi=EPI_F32_SLAB, splits=St, **kw)
+            ops.reduce_slabs(slab, n_el, St, gw, n_el, accumulate=True)
 
     if defer is not None:
         pass
@@ -837,7 +803,7 @@ class Stack:
         # grouped weight gradients: the four dW of block i are ONE launch (split-K combine and bias-gradient column sums inside
         # it), issued at the start of block i - 1's backward so that it overlaps that block's dgrad / attention kernels; the dy
         # operands it reads (dpre, dmid_b, dqkv; dy_b already alternates) are therefore double-buffered by block parity
-        grouped = WGRAD_GROUPED and WGRAD_TN and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks)
+        grouped = WGRAD_GROUPED and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks)
         par = (lambda i: f".{i & 1}") if grouped else (lambda i: "")
         dh = ws.get("b.dh", (M, H), BF)
         d_o = ws.get("b.do", (M, D), BF)
@@ -871,18 +837,15 @@ class Stack:
             if grouped:
                 launch_pending()  # dW of block i + 1, beside this block's kernels
             # ---- FFN: x_out = x_mid + w3(act(...))
-            fuse = os.environ.get("VTP_SWIGLU_BIAS_FUSED", "0") == "1" and not grouped
-            fused_act = vit and FUSE_SWIGLU_BWD and b.ls2 is None and not fuse
+            fused_act = vit and FUSE_SWIGLU_BWD and b.ls2 is None
             linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dpre if fused_act else dh,
                        bias_grad_done=dy_colsum_done if i == self.depth - 1 else self.w3_colsum_target(i) is not None,
                        ls=(b.ls2, b.gls2) if b.ls2 is not None else None, dgrad_swiglu=pre if fused_act else None, defer=probs)
             if vit:
                 if not fused_act:
-                    # the kernel can also accumulate the w1 / w2 bias gradients (db12), but its 1 M atomics per launch cost more
-                    # than the separate column-sum pass on the side stream (same-box A/B: 536 vs 542 images/s): off by default
-                    ops.swiglu_bwd(dh, pre, dpre, M, H, db12=b.w12.gb1 if fuse else None)
+                    ops.swiglu_bwd(dh, pre, dpre, M, H)
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
-                           swiglu_h=H, bias_grad_done=fuse, defer=probs)
+                           swiglu_h=H, defer=probs)
             else:
                 ops.gelu_bwd(dh, pre, dpre, M * H)
                 linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn, defer=probs)

@@ -553,7 +553,7 @@ class VTPTrainer:
         xnf = xnf_all[:Bc * Nc]  # rows of the clip item (item 0; the shared item when rec and clip see the same pass)
         # the text tower's GEMMs are small (M = 77 B rows): it is issued on its own stream (with its own wgrad side stream,
         # OVERLAP lane 1) so that it runs concurrently with the decoder forward / the first decoder-backward blocks
-        par_text = text is not None and OVERLAP.enabled and os.environ.get("VTP_TEXT_STREAM", "1") != "0"
+        par_text = text is not None and OVERLAP.enabled
         par_fwd = par_bwd = par_text
         main = torch.cuda.current_stream()
         if par_text:
