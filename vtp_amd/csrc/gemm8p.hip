@@ -459,15 +459,20 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         for (int z = 0; z < gt.splits; ++z) {
           if (z == zslice) continue;
           const f32x4* other = (const f32x4*)gt.part + (((size_t)gt.tile * gt.splits + z) * 8 + wave) * 2048 + lane;
+          // NL loads in flight per lane (the fragment registers are dead here); the NT epilogues keep more values live across the
+          // combine (bias, residual prefetch), so they take the partials in smaller bites
+          constexpr int NL = TRANS ? 16 : 8;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {  // 16 loads (64 registers) in flight per lane; the fragment registers are dead here
-            f32x4 v[16];
+          for (int g = 0; g < 32 / NL; ++g) {
+            f32x4 v[NL];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = other[(i * 16 + t) * 64];
+            for (int t = 0; t < NL; ++t) v[t] = other[(g * NL + t) * 64];
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
+            for (int t = 0; t < NL; ++t) {
+              const int u = g * NL + t;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[i][t >> 2][4 * (t & 3) + e] += v[t][e];
+              for (int e = 0; e < 4; ++e) acc[u >> 4][(u >> 2) & 3][4 * (u & 3) + e] += v[t][e];
+            }
             asm volatile("" ::: "memory");
           }
         }

@@ -106,6 +106,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
       const int r = lane & 31;
       constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
+      // the lane's bias values do not depend on the row block: ONE round of loads per tile (in front of the first block's
+      // conversions) instead of one L2 round trip inside every block
+      f32x4 bias_v[TN][4];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
+          bias_v[i][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         // fused SwiGLU backward: this block's x1 | x2 pre-activations are requested BEFORE the accumulators go through LDS, so the
@@ -125,11 +135,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int nl = i * 32 + 8 * q + 4 * hi, n = n0 + wn * WTN + nl;
+            const int nl = i * 32 + 8 * q + 4 * hi;
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-            if (p.bias && n < p.N) v += *(const f32x4*)(p.bias + n);
+            v += bias_v[i][q];
             *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
           }
 #pragma unroll
@@ -187,6 +197,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int RB = WTN * 2, CPR = RB / 16, RBH = WTN, CPRH = RBH / 16;
       static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
       const int r = lane & 31;
+      f32x4 bias_v[TN][4];  // one round of bias loads per tile (see the bf16 path)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
+          bias_v[i][q] = n < p.N ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         bf16x4 hs[TN][2];
@@ -194,11 +212,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {
-            const int nl = i * 32 + 8 * q + 4 * hi, n1 = n0 + wn * WTN + nl;
+            const int nl = i * 32 + 8 * q + 4 * hi;
             f32x4 x1, x2, hsw;
-            const bool ok = n1 < p.N;
-            const f32x4 b1 = ok ? *(const f32x4*)(p.bias + n1) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 b2 = ok ? *(const f32x4*)(p.bias + n1 + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = bias_v[i][q], b2 = bias_v[i][q + 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               x1[e] = acc[i][j][4 * q + e] * p.alpha + b1[e];
@@ -268,6 +284,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
         }
       };
       fetch(0, rv[0]);
+      // bias / LayerScale values of the lane's columns: the column of item t is the same for every t and row block (64 % CPR == 0),
+      // so they are loaded once per column group instead of inside every pass
+      static_assert(64 % CPR == 0, "a lane's column must not depend on t");
+      f32x4 bs[TN / IG], gm[TN / IG];
+#pragma unroll
+      for (int ig = 0; ig < TN / IG; ++ig) {
+        const int n = n0 + wn * WTN + ig * IG * 32 + (lane % CPR) * 4;
+        bs[ig] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gm[ig] = (p.gamma && n < p.N) ? *(const f32x4*)(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         const int j = pass / (TN / IG), ig = pass % (TN / IG);
@@ -289,9 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           coords(pass, t, m, n);
           if (m < p.M && n < p.N) {
             const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
-            if (p.bias) v += *(const f32x4*)(p.bias + n);
-            if (p.gamma) v *= *(const f32x4*)(p.gamma + n);
-            v += rv[pass & 1][t];
+            v = (v + bs[ig]) * gm[ig] + rv[pass & 1][t];
             *(f32x4*)((float*)p.C + off) = v;
           }
         }
