@@ -479,7 +479,10 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       }
     }
     char* reg = gemm_epilogue_uses_lds<EPI, TRANS, 64, P8_REGION>(p) ? smem + P8_RING + wave * P8_REGION : nullptr;
-    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION, XMODE>(p, acc, reg, m0, n0, wr, wc, lane, zslice);
+    // the ring slot under the staging cursor is free (its half-tile was consumed >= 2 phases ago, the next LDS-DMA into it is issued
+    // after this epilogue): the wave's own 2 KiB of it are a second staging region
+    char* reg2 = (EPI == EPI_SWIGLU && reg) ? smem + s_dst : nullptr;
+    gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION, XMODE>(p, acc, reg, m0, n0, wr, wc, lane, zslice, reg2);
     stamp(ti, 2);
     zero_acc();
   }

@@ -82,15 +82,26 @@ __device__ __forceinline__ bool gemm_epilogue_uses_lds(const GemmArgs& p) {
 // Epilogue of one wave: acc[i][j] = 32x32 fp32 tile (i over the wave's WTN / 32 column blocks, j over its WTM / 32 row blocks)
 // of the output tile at (m0, n0); the wave's sub-tile starts at row wm * WTM, column wn * WTN.  MFMA operands were swapped
 // (weight rows = A operand), so a lane holds, for output row m = .. + (lane & 31), columns nb + 8*q + 4*hi + (0..3), q = 0..3.
-// reg: this wave's private LDS staging region of REGION bytes (or null: direct stores).
+// reg: this wave's private LDS staging region of REGION bytes (or null: direct stores); reg2: a second private region of
+// REGION / 2 bytes (or null) -- with it the SwiGLU epilogue stages a row block's pre-activations and hidden values side by side
+// (one LDS write -> read -> store chain per block instead of two back to back).
 // XMODE (bf16 epilogue only): which fused extra the LDS-staged store path carries -- -1: decided at run time from the argument block
 // (the ring kernels) | 0: none | 1: apply_rope (rope_pos) | 2: SwiGLU backward (swiglu_pre).  The 256 x 256 kernel instantiates
 // 0 / 1 / 2 separately: the plain variant then carries neither the extras' registers (the pre-activation prefetch alone is 32)
 // nor conditionally waited loads that make hipcc drain `vmcnt(0)` at the head of the k loop.
 template <int EPI, bool TRANS, int WTM, int WTN, int REGION, int XMODE = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[WTN / 32][WTM / 32], char* reg, int m0, int n0,
-                                              int wm, int wn, int lane, int zslice = blockIdx.z) {
+                                              int wm, int wn, int lane_in, int zslice = blockIdx.z, char* reg2 = nullptr) {
+  int lane = lane_in;
   constexpr int TM = WTM / 32, TN = WTN / 32;
+  // Everything the epilogue derives from the lane id (rows, swizzled LDS offsets, column offsets: ~35 registers) is invariant over
+  // the persistent tile loop, so hipcc hoists it in front of that loop, cannot keep it in registers through the k loop, and spills
+  // it -- and every scratch reload inside the store loops below is followed by `s_waitcnt vmcnt(0)`, i.e. drains all the global
+  // stores issued so far AND the LDS-DMA prefetch of the next tile (measured: 4.5 us of a bf16 epilogue, 12.8 us of the SwiGLU
+  // one).  An opaque copy of the lane id per tile keeps those values tile-local: recomputed with a few VALU, never spilled.
+  // (not for the fp32-residual epilogue and the SwiGLU-backward variant: their own live sets -- residual / pre-activation
+  // prefetch -- leave no room to recompute; measured slower with it)
+  if constexpr (EPI != EPI_F32 && XMODE != 2) asm volatile("" : "+v"(lane));
   const int hi = lane >> 5;
   const bool x_rope = XMODE < 0 ? p.rope_pos != nullptr : XMODE == 1;
   const bool x_swiglu = XMODE < 0 ? p.swiglu_pre != nullptr : XMODE == 2;
@@ -108,14 +119,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
       // the lane's bias values do not depend on the row block: ONE round of loads per tile (in front of the first block's
       // conversions) instead of one L2 round trip inside every block
-      f32x4 bias_v[TN][4];
+      constexpr bool HAS_BIAS = XMODE != 2;  // (the SwiGLU-backward instantiation is a dgrad: no bias, and no registers for one)
+      f32x4 bias_v[HAS_BIAS ? TN : 1][4];
+      if constexpr (HAS_BIAS) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
-          bias_v[i][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
+            bias_v[i][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         // fused SwiGLU backward: this block's x1 | x2 pre-activations are requested BEFORE the accumulators go through LDS, so the
@@ -139,7 +153,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-            v += bias_v[i][q];
+            if constexpr (HAS_BIAS) v += bias_v[i][q];
             *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
           }
 #pragma unroll
@@ -229,6 +243,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
               *(bf16x4*)(reg + r * RB + ((((nl >> 3) + 1) ^ (r & (CPR - 1))) << 4) + hi * 8) = x2b;
             }
           }
+        char* regh = reg2 ? reg2 : reg;  // hidden block: its own region when there is one (written before x12 is read back)
+        auto write_hidden = [&]() {      // local column (2i + q/2)*8 + 4hi of a [32][WTN/2] block
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+              *(bf16x4*)(regh + r * RBH + ((((2 * i + h2)) ^ (r & (CPRH - 1))) << 4) + hi * 8) = hs[i][h2];
+        };
+        if (reg2) write_hidden();
         if (p.C2) {
 #pragma unroll
           for (int t = 0; t < 32 * CPR / 64; ++t) {
@@ -238,16 +261,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C2 + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc2 + n) = val;
           }
         }
-        // hidden: local column (2i + q/2)*8 + 4hi of a [32][WTN/2] block
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2)
-            *(bf16x4*)(reg + r * RBH + ((((2 * i + h2)) ^ (r & (CPRH - 1))) << 4) + hi * 8) = hs[i][h2];
+        if (!reg2) write_hidden();
 #pragma unroll
         for (int t = 0; t < 32 * CPRH / 64; ++t) {
           const int idx = t * 64 + lane, rr = idx / CPRH, c = idx % CPRH;
-          const bf16x8 val = *(const bf16x8*)(reg + rr * RBH + ((c ^ (rr & (CPRH - 1))) << 4));
+          const bf16x8 val = *(const bf16x8*)(regh + rr * RBH + ((c ^ (rr & (CPRH - 1))) << 4));
           const int m = m0 + wm * WTM + j * 32 + rr, jh = ((n0 + wn * WTN) >> 1) + c * 8;
           if (m < p.M && 2 * jh < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + jh) = val;
         }
@@ -265,8 +283,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int RB = IG * 128, CPR = RB / 16;
       constexpr int T = 32 * CPR / 64, NPASS = TM * (TN / IG);
       const int r = lane & 31;
-      // the residual rows of pass k + 1 are requested before pass k goes through LDS: one HBM round trip per tile is exposed
-      // instead of one per pass (the dominant cost of this epilogue at K = 768: 8 dependent round trips per 256x256 tile)
+      // the residual rows of pass k + 1 are requested before pass k goes through LDS (they are then OLDER than pass k's stores in the
+      // in-order VMEM queue: waiting for them does not wait for those stores): one HBM round trip per tile is exposed instead of one
+      // per pass (the dominant cost of this epilogue at K = 768: 8 dependent round trips per 256x256 tile)
       f32x4 rv[2][T];
       auto coords = [&](int pass, int t, int& m, int& n) {
         const int j = pass / (TN / IG), ig = pass % (TN / IG);
