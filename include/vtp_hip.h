@@ -75,6 +75,10 @@ int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
  * (0 = every CU); delay_ticks > 0 starts every second workgroup of an XCD that many 10-ns ticks late (lock-step experiments).
  * Process-global; not part of the reference-facing surface. */
 int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks);
+/* diagnostics (tools/attn_bwd_timeline.py): `timing` = device buffer of 2 x [workgroups][16 waves][4] 64-bit s_memrealtime stamps
+ * {start, operands staged, loop done, gradients stored} written by the resident attention backward kernels (dQ kernel, then the
+ * dK/dV kernel), null = off.  Process-global; not part of the reference-facing surface. */
+int vtp_attn_debug(void* timing, int lds_pad, int waves_per_wg, int stagger_ticks);  /* lds_pad: extra dynamic LDS bytes per workgroup; waves_per_wg: 0 = heuristic */
 int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);

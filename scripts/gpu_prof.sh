@@ -4,7 +4,7 @@ export PYTHONDONTWRITEBYTECODE=1
 R=$PWD
 mkdir -p $R/gpurun_out/prof_full
 cd /tmp && export TMPDIR=/tmp
-VTP_OVERLAP=${VTP_OVERLAP:-1} timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_full -o full -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-lpips-run --no-graphs > $R/gpurun_out/prof_full.log 2>&1
+VTP_OVERLAP=${VTP_OVERLAP:-1} timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_full -o full -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-lpips-run --no-separate-run --no-graphs > $R/gpurun_out/prof_full.log 2>&1
 echo "prof rc=$?"
 cd $R
 ls gpurun_out/prof_full | head

@@ -217,7 +217,10 @@ def _attn_ref(q, k, v, causal):
                                               (1, 1025, 2, False), (2, 130, 1, True), (1, 64, 1, False),
                                               # the launches of the benchmarked list forward (VTP-B, 12 heads): local 96^2 crops
                                               # (N = 37) and the merged clean-image + global-crop segment (32 + 64 images, N = 257)
-                                              (16, 37, 12, False), (96, 257, 12, False)])
+                                              (16, 37, 12, False), (96, 257, 12, False),
+                                              # persistent backward kernels: two rows in the odd 9th block, several heads per
+                                              # workgroup at 8 row blocks, the last block partly filled
+                                              (3, 258, 2, False), (40, 256, 8, False), (2, 230, 2, False)])
 def test_attention_fwd_bwd(B, N, heads, causal):
     o = ops()
     D = heads * 64

@@ -35,7 +35,16 @@ struct AttnResArgs {
   int B, N, heads, npad;  // npad = N rounded up to 32
   long sb, sn, sbo, sno;
   float scale;
+  int stagger;            // experiment: start every second workgroup of the first round this many 10-ns ticks late
+  long long* timing;      // diagnostics (vtp_attn_debug): [workgroup][16 waves][4] s_memrealtime stamps of the backward kernels, or null
 };
+
+// phase stamps of the backward kernels: 0 start, 1 operands staged, 2 loop done, 3 gradients stored
+#define BWD_STAMP(i)                                                                                                     \
+  do {                                                                                                                   \
+    if (__builtin_expect(p.timing != nullptr, 0) && lane == 0)                                                           \
+      p.timing[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave) * 4 + (i)] = wall_clock64(); \
+  } while (0)
 
 __device__ __forceinline__ int swz_key(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
@@ -67,6 +76,34 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* lds, int dblk, int row0, i
   const char* p1 = lds + (r + 8) * 128 + (((col >> 3) ^ swz_key(r + 8)) << 4) + ((col & 7) << 1);
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
   bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+  return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// The same two fragment reads with the address split into a per-lane part (loop-invariant VGPR) and a wave-uniform part (SGPR, the
+// row block of the current step), added by an instruction the compiler cannot look through: left to itself hipcc strength-reduces
+// every fragment address into its own VGPR incremented per step -- 18 address registers in the dK/dV loop, which pushed it over
+// the 168-VGPR budget of three waves per SIMD and put a scratch reload (with a full vmcnt(0) drain) into every step.
+//   row fragment:  lane part row_part(lane) ^ (ks << 5)           (the chunk swizzle is an XOR, ks selects bits 5..6)
+//   tr fragment:   lane part tr_part(lane, half) ^ (dblk << 6)    (half = rows +0 / +8), + ks * 2048 as immediate
+__device__ __forceinline__ int row_part(int lane) {
+  const int r = lane & 31;
+  return r * 128 + (((lane >> 5) ^ swz_key(r)) << 4);
+}
+__device__ __forceinline__ int tr_part(int lane, int half) {
+  const int i = lane & 15, g = (lane >> 4) & 1, hi = lane >> 5;
+  const int r = hi * 4 + (i >> 2) + 8 * half;
+  const int col = g * 16 + (i & 3) * 4;
+  return r * 128 + (((col >> 3) ^ swz_key(r)) << 4) + ((col & 7) << 1);
+}
+__device__ __forceinline__ int lds_addr(int lane_part, int uniform_part) {
+  int a;
+  asm("v_add_u32 %0, %1, %2" : "=v"(a) : "s"(uniform_part), "v"(lane_part));
+  return a;
+}
+__device__ __forceinline__ bf16x8 frag_row_at(int addr) { return *(const __attribute__((address_space(3))) bf16x8*)(size_t)addr; }
+__device__ __forceinline__ bf16x8 frag_tr_at(int addr0, int addr1, int ks) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(size_t)(addr0 + ks * 2048));
+  bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(size_t)(addr1 + ks * 2048));
   return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -544,6 +581,14 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   char* Vs = smem + p.npad * 128;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, hi = lane >> 5;
   const int h = blockIdx.x, b = blockIdx.y;
+  BWD_STAMP(0);
+  if (__builtin_expect(p.stagger > 0, 0)) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 256 && ((wg >> 3) & 1)) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   stage_resident(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Ks, wave, nwaves, lane);
   stage_resident(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Vs, wave, nwaves, lane);
   const int q0 = (blockIdx.z * nwaves + wave) * 32, qi = q0 + (lane & 31), qc = min(qi, p.N - 1);
@@ -573,6 +618,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
   }
   wait_all_dma();
   __syncthreads();
+  BWD_STAMP(1);
   if (q0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
   const f32x2 sc2v = {sc2, sc2}, nlse = {-lse2, -lse2}, scv = {p.scale, p.scale}, ndlt = {-dlt * p.scale, -dlt * p.scale};
@@ -614,7 +660,8 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
       dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, db, kb * 32, 1, lane), d1, dq[db], 0, 0, 0);
     }
   }
-  if (qi >= p.N) return;
+  BWD_STAMP(2);
+  if (qi < p.N) {
   bf16* drow = p.dq + (long)b * p.sb + (long)qi * p.sn + h * 64;
   const bool rot = p.rope_sin && qi >= p.rope_prefix;
   const long t = (long)(qi - p.rope_prefix) * 64;
@@ -628,6 +675,8 @@ __global__ __launch_bounds__(640) void attn_bwd_dq_res_kernel(const AttnResArgs 
     }
     store_grad_pair(drow, 8 * g + 4 * hi, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos, t);
   }
+  }
+  BWD_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -639,6 +688,14 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   float* dlt_s = lse_s + p.npad;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, hi = lane >> 5;
   const int h = blockIdx.x, b = blockIdx.y;
+  BWD_STAMP(0);
+  if (__builtin_expect(p.stagger > 0, 0)) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 256 && ((wg >> 3) & 1)) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   stage_resident(p.q + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, Qs, wave, nwaves, lane);
   stage_resident(p.d_o + (long)b * p.sbo + h * 64, p.sno, p.N, p.npad, Gs, wave, nwaves, lane);
   const long srow0 = ((long)b * p.heads + h) * p.N;
@@ -660,6 +717,7 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   }
   wait_all_dma();
   __syncthreads();
+  BWD_STAMP(1);
   if (k0 >= p.npad) return;
   const float sc2 = p.scale * LOG2E_R;
   const f32x2 sc2v = {sc2, sc2}, scv = {p.scale, p.scale};
@@ -669,14 +727,25 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
   zero16r(dk[1]);
   zero16r(dv[0]);
   zero16r(dv[1]);
+  // per-lane parts of the fragment addresses (8 VGPRs for the whole loop; LDS addresses are offsets: the dynamic segment is the
+  // kernel's only LDS)
+  int rpart[4], tpart[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rpart[ks] = row_part(lane) ^ (ks << 5);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) tpart[db][hf] = tr_part(lane, hf) ^ (db << 6);
+  const int g_off = p.npad * 128;
   for (int qblk = 0; qblk < nqb; ++qblk) {
     f32x16 s, dp;
     zero16r(s);
     zero16r(dp);
+    const int q_off = __builtin_amdgcn_readfirstlane(qblk * 4096);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qs, qblk * 32, ks, lane), kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Gs, qblk * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], q_off)), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], q_off + g_off)), vf[ks], dp, 0, 0, 0);
     }
     f32x16 pr;
 #pragma unroll
@@ -705,13 +774,16 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
     const bf16x8 p0 = pack8r(pr, 0), p1 = pack8r(pr, 8), d0 = pack8r(s, 0), d1 = pack8r(s, 8);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, db, qblk * 32, 0, lane), p0, dv[db], 0, 0, 0);
-      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, db, qblk * 32, 1, lane), p1, dv[db], 0, 0, 0);
-      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, db, qblk * 32, 0, lane), d0, dk[db], 0, 0, 0);
-      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, db, qblk * 32, 1, lane), d1, dk[db], 0, 0, 0);
+      const int tq0 = lds_addr(tpart[db][0], q_off), tq1 = lds_addr(tpart[db][1], q_off);
+      const int tg0 = lds_addr(tpart[db][0], q_off + g_off), tg1 = lds_addr(tpart[db][1], q_off + g_off);
+      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tg0, tg1, 0), p0, dv[db], 0, 0, 0);
+      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tg0, tg1, 1), p1, dv[db], 0, 0, 0);
+      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tq0, tq1, 0), d0, dk[db], 0, 0, 0);
+      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tq0, tq1, 1), d1, dk[db], 0, 0, 0);
     }
   }
-  if (ki >= p.N) return;
+  BWD_STAMP(2);
+  if (ki < p.N) {
   bf16* krow = p.dk + (long)b * p.sb + (long)ki * p.sn + h * 64;
   bf16* vrow = p.dv + (long)b * p.sb + (long)ki * p.sn + h * 64;
   const bool rot = p.rope_sin && ki >= p.rope_prefix;
@@ -729,6 +801,343 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
     store_grad_pair(krow, 8 * g + 4 * hi, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos, t);
     store_grad_pair(vrow, 8 * g + 4 * hi, c0, c1, nullptr, nullptr, 0);
   }
+  }
+  BWD_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------------ backward, fused
+// N = 225 .. 258 (the 257-token passes of the trunk and the 256-token decoder: 8 row blocks, or 8 + a 9th with one or two rows).
+// What the two per-head kernels above lose at these sizes (tools/attn_bwd_timeline.py, profiles/r03_attn_bwd_timeline.log):
+//   * 9 equal waves on 4 SIMDs: the SIMD with three of them sets the workgroup's time (loop 9.0 us vs 3.9 us for its fastest wave);
+//   * more than half of a workgroup's 18 .. 23 us is not the loop: every lane fetches its own q / dO / O (or k / v) row as 16-B
+//     pieces of 32 different 4.6-KB-strided rows per instruction (6 .. 7 us until the operands have arrived, alone on the chip
+//     still 3 .. 4 us), and each of q, k, v, dO crosses HBM twice (once per kernel, once as LDS image, once as rows).
+// Here ONE workgroup of 8 waves (two per SIMD, up to 256 VGPRs) per head stages the four images Q, K, V, dO (4 x 36 KB) by LDS-DMA
+// -- whole 128-B lines, every tensor read once -- and runs both products from them: phase 1 the lane is a query (wave w = query
+// block w: dQ), phase 2 the lane is a key (wave w = key block w: dK, dV); the row operands of either phase are fragments of the
+// images, delta and lse pass from phase 1 to phase 2 through LDS.  The rows of the odd 9th block are spread: wave w computes the
+// 9th block's contribution against block w (wave 0 also against block 8) after its own loop, the partial sums travel through LDS
+// slots [block][row][64] and are added in block order (deterministic) by the threads that store them.
+constexpr int PB_WAVES = 8;
+constexpr int PB_XROWS = 2;  // rows of the odd 9th block (N - 256 <= 2)
+
+__device__ __forceinline__ int stage_image_asm(const bf16* base, long sn, int N, int npad, unsigned img_off, int wave, int lane) {
+  int n = 0;
+  for (int piece = wave; piece < (npad >> 3); piece += PB_WAVES, ++n) stage_piece_asm(base, sn, N, piece, img_off, lane);
+  return n;
+}
+
+// one (query block, key block) step of the dQ computation, the lane being a query: s / dp from the K / V row fragments at LDS
+// offset `koff` (V image `img` bytes behind), dS, and dq += dS K through the transposed fragments
+__device__ __forceinline__ void dq_step(const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], f32x16 (&dq)[2], const int (&rpart)[4],
+                                        const int (&tpart)[2][2], int koff, int img, f32x2 sc2v, f32x2 nlse, f32x2 scv, f32x2 ndlt,
+                                        int key0, int N, bool mask, int hi) {
+  f32x16 s, dp;
+  zero16r(s);
+  zero16r(dp);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], koff)), qf[ks], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], koff + img)), dof[ks], dp, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2 e = {s[2 * i], s[2 * i + 1]}, g = {dp[2 * i], dp[2 * i + 1]};
+    e = __builtin_elementwise_fma(e, sc2v, nlse);
+    g = __builtin_elementwise_fma(g, scv, ndlt);
+    e[0] = fast_exp2(e[0]);
+    e[1] = fast_exp2(e[1]);
+    e *= g;
+    s[2 * i] = e[0];
+    s[2 * i + 1] = e[1];
+  }
+  if (mask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) s[r] = 0.f;
+  }
+  const bf16x8 d0 = pack8r(s, 0), d1 = pack8r(s, 8);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int t0 = lds_addr(tpart[db][0], koff), t1 = lds_addr(tpart[db][1], koff);
+    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(t0, t1, 0), d0, dq[db], 0, 0, 0);
+    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(t0, t1, 1), d1, dq[db], 0, 0, 0);
+  }
+}
+
+// delta = rowsum(dO * O) of this lane's query (summed over the two half-waves)
+__device__ __forceinline__ float row_delta(const bf16x8 (&of)[4], const bf16x8 (&dof)[4]) {
+  float dlt = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dlt += bf2f(of[ks][e]) * bf2f(dof[ks][e]);
+  return dlt + __shfl_xor(dlt, 32, 64);
+}
+
+#define PB_STAMP(i)                                                                                                   \
+  do {                                                                                                                \
+    if (__builtin_expect(p.timing != nullptr, 0) && lane == 0) p.timing[((size_t)hid * 16 + wave) * 4 + (i)] = wall_clock64(); \
+  } while (0)
+
+// one (key block, query block) step of the dK / dV computation, the lane being a key: s / dp from the Q / dO row fragments at LDS
+// offset `qoff` (dO image `img` bytes behind), P and dS with the per-query -lse / -delta from LDS, dv += dO^T P, dk += Q^T dS
+__device__ __forceinline__ void dkv_step(const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dk)[2], f32x16 (&dv)[2],
+                                         const int (&rpart)[4], const int (&tpart)[2][2], int qoff, int img, const float* lse_s,
+                                         const float* dlt_s, f32x2 sc2v, f32x2 scv, int q0, int N, bool mask, int hi) {
+  f32x16 s, dp;
+  zero16r(s);
+  zero16r(dp);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], qoff)), kf[ks], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row_at(lds_addr(rpart[ks], qoff + img)), vf[ks], dp, 0, 0, 0);
+  }
+  f32x16 pr;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 l4 = *(const f32x4*)(lse_s + q0 + 8 * g + 4 * hi);  // -lse * log2(e) of the four query rows
+    const f32x4 d4 = *(const f32x4*)(dlt_s + q0 + 8 * g + 4 * hi);  // -delta * scale
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2) {
+      const int r = 4 * g + 2 * e2;
+      f32x2 e = {s[r], s[r + 1]}, gq = {dp[r], dp[r + 1]};
+      e = __builtin_elementwise_fma(e, sc2v, f32x2{l4[2 * e2], l4[2 * e2 + 1]});
+      gq = __builtin_elementwise_fma(gq, scv, f32x2{d4[2 * e2], d4[2 * e2 + 1]});
+      e[0] = fast_exp2(e[0]);
+      e[1] = fast_exp2(e[1]);
+      if (mask) {
+        if (q0 + 8 * g + 4 * hi + 2 * e2 >= N) e[0] = 0.f;
+        if (q0 + 8 * g + 4 * hi + 2 * e2 + 1 >= N) e[1] = 0.f;
+      }
+      pr[r] = e[0];
+      pr[r + 1] = e[1];
+      e *= gq;
+      s[r] = e[0];
+      s[r + 1] = e[1];
+    }
+  }
+  const bf16x8 p0 = pack8r(pr, 0), p1 = pack8r(pr, 8), d0 = pack8r(s, 0), d1 = pack8r(s, 8);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int tq0 = lds_addr(tpart[db][0], qoff), tq1 = lds_addr(tpart[db][1], qoff);
+    const int tg0 = lds_addr(tpart[db][0], qoff + img), tg1 = lds_addr(tpart[db][1], qoff + img);
+    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tg0, tg1, 0), p0, dv[db], 0, 0, 0);
+    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tg0, tg1, 1), p1, dv[db], 0, 0, 0);
+    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tq0, tq1, 0), d0, dk[db], 0, 0, 0);
+    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_at(tq0, tq1, 1), d1, dk[db], 0, 0, 0);
+  }
+}
+
+// the 9th block's rows of one gradient: partial sums of the row blocks -> slots; the storing threads add them in block order
+__device__ __forceinline__ void put_slot(float* slot, const f32x16 (&acc)[2], int hi) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[db][4 * g + e];
+      *(f32x4*)(slot + 32 * db + 8 * g + 4 * hi) = v;
+    }
+}
+__device__ __forceinline__ void store_acc_rows(bf16* row, const f32x16 (&acc)[2], int hi, const bf16* sin_t, const bf16* cos_t, long t) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 lo, hv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = acc[0][4 * g + e];
+      hv[e] = acc[1][4 * g + e];
+    }
+    store_grad_pair(row, 8 * g + 4 * hi, lo, hv, sin_t, cos_t, t);
+  }
+}
+
+__global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const AttnResArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  const int img = p.npad * 128, nb = p.npad >> 5, last = nb - 1;
+  const bool odd = nb > PB_WAVES;
+  const int nx = odd ? p.N - 32 * PB_WAVES : 0;  // valid rows of the 9th block
+  // LDS: Q | K | V | dO images, then -lse log2(e) and -delta scale per query, then the slots of the 9th block's dq, dk, dv rows
+  const int QO = 0, KO = img, VO = 2 * img, GO = 3 * img;
+  float* lse_s = (float*)(smem + 4 * img);
+  float* dlt_s = lse_s + p.npad;
+  float* xq = dlt_s + p.npad;           // [9][PB_XROWS][64]
+  float* xk = xq + 9 * PB_XROWS * 64;
+  float* xv = xk + 9 * PB_XROWS * 64;
+  const int hid = blockIdx.x, b = hid / p.heads, h = hid - b * p.heads;
+  PB_STAMP(0);
+  stage_image_asm(p.q + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, QO, wave, lane);
+  stage_image_asm(p.d_o + (long)b * p.sbo + h * 64, p.sno, p.N, p.npad, GO, wave, lane);
+  stage_image_asm(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, KO, wave, lane);
+  stage_image_asm(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, VO, wave, lane);
+  const float sc2 = p.scale * LOG2E_R;
+  const f32x2 sc2v = {sc2, sc2}, scv = {p.scale, p.scale};
+  int rpart[4], tpart[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rpart[ks] = row_part(lane) ^ (ks << 5);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) tpart[db][hf] = tr_part(lane, hf) ^ (db << 6);
+  const long srow0 = ((long)b * p.heads + h) * p.N;
+  const int ri = wave * 32 + (lane & 31);                     // this lane's row of block `wave` (query in phase 1, key in phase 2)
+  const int rx = 32 * PB_WAVES + (lane & 31);                 // ... and of the 9th block
+  // O rows and lse of this lane's queries (the only per-lane global loads left)
+  bf16x8 of[4], of2[4];
+  float lse_raw, lse_raw2 = 0.f;
+  {
+    const int qc = min(ri, p.N - 1);
+    const bf16* orow = p.o + (long)b * p.sbo + h * 64 + (long)qc * p.sno + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) of[ks] = *(const bf16x8*)(orow + ks * 16);
+    lse_raw = p.lse[srow0 + qc];
+    if (odd) {
+      const int qc2 = min(rx, p.N - 1);
+      const bf16* orow2 = p.o + (long)b * p.sbo + h * 64 + (long)qc2 * p.sno + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) of2[ks] = *(const bf16x8*)(orow2 + ks * 16);
+      lse_raw2 = p.lse[srow0 + qc2];
+    }
+  }
+  wait_all_dma();
+  __syncthreads();
+  PB_STAMP(1);
+  // ------------------------------------------------------------------------------------------ phase 1: dQ (the lane is a query)
+  {
+    bf16x8 qf[4], dof[4];
+    const int own = __builtin_amdgcn_readfirstlane(wave * 4096);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = frag_row_at(lds_addr(rpart[ks], QO + own));
+      dof[ks] = frag_row_at(lds_addr(rpart[ks], GO + own));
+    }
+    const float dlt = row_delta(of, dof);
+    if (hi == 0) {
+      lse_s[ri] = -lse_raw * LOG2E_R;
+      dlt_s[ri] = -dlt * p.scale;
+      if (ri < p.N) p.delta[srow0 + ri] = dlt;
+    }
+    {
+      const float lse2 = lse_raw * LOG2E_R;
+      const f32x2 nlse = {-lse2, -lse2}, ndlt = {-dlt * p.scale, -dlt * p.scale};
+      f32x16 dq[2];
+      zero16r(dq[0]);
+      zero16r(dq[1]);
+      for (int kb = 0; kb < nb; ++kb)
+        dq_step(qf, dof, dq, rpart, tpart, __builtin_amdgcn_readfirstlane(KO + kb * 4096), img, sc2v, nlse, scv, ndlt, kb * 32, p.N,
+                kb == last && (p.N & 31), hi);
+      if (ri < p.N) {
+        const bool rot = p.rope_sin && ri >= p.rope_prefix;
+        store_acc_rows(p.dq + (long)b * p.sb + (long)ri * p.sn + h * 64, dq, hi, rot ? p.rope_sin : nullptr, p.rope_cos,
+                       (long)(ri - p.rope_prefix) * 64);
+      }
+    }
+    if (odd) {  // the 9th block's queries against key block `wave` (wave 0: and against the 9th key block)
+      const int ox = __builtin_amdgcn_readfirstlane(PB_WAVES * 4096);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = frag_row_at(lds_addr(rpart[ks], QO + ox));
+        dof[ks] = frag_row_at(lds_addr(rpart[ks], GO + ox));
+      }
+      const float dlt2 = row_delta(of2, dof);
+      if (wave == 0 && hi == 0) {
+        lse_s[rx] = -lse_raw2 * LOG2E_R;
+        dlt_s[rx] = -dlt2 * p.scale;
+        if (rx < p.N) p.delta[srow0 + rx] = dlt2;
+      }
+      const float lse2 = lse_raw2 * LOG2E_R;
+      const f32x2 nlse = {-lse2, -lse2}, ndlt = {-dlt2 * p.scale, -dlt2 * p.scale};
+      for (int kb = wave; kb < nb; kb += PB_WAVES) {
+        f32x16 dqx[2];
+        zero16r(dqx[0]);
+        zero16r(dqx[1]);
+        dq_step(qf, dof, dqx, rpart, tpart, __builtin_amdgcn_readfirstlane(KO + kb * 4096), img, sc2v, nlse, scv, ndlt, kb * 32, p.N,
+                kb == last && (p.N & 31), hi);
+        if ((lane & 31) < nx) put_slot(xq + (kb * PB_XROWS + (lane & 31)) * 64, dqx, hi);
+      }
+    }
+  }
+  __syncthreads();  // lse_s / dlt_s and the 9th block's dq slots are complete
+  PB_STAMP(2);
+  if (odd && (int)threadIdx.x < nx * 8) {
+    const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), qrow = 32 * PB_WAVES + row;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nb; ++kb) {
+      lo += *(const f32x4*)(xq + (kb * PB_XROWS + row) * 64 + d0);
+      hv += *(const f32x4*)(xq + (kb * PB_XROWS + row) * 64 + 32 + d0);
+    }
+    const bool rot = p.rope_sin && qrow >= p.rope_prefix;
+    store_grad_pair(p.dq + (long)b * p.sb + (long)qrow * p.sn + h * 64, d0, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos,
+                    (long)(qrow - p.rope_prefix) * 64);
+  }
+  // ------------------------------------------------------------------------------------------ phase 2: dK, dV (the lane is a key)
+  {
+    bf16x8 kf[4], vf[4];
+    const int own = __builtin_amdgcn_readfirstlane(wave * 4096);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_row_at(lds_addr(rpart[ks], KO + own));
+      vf[ks] = frag_row_at(lds_addr(rpart[ks], VO + own));
+    }
+    {
+      f32x16 dk[2], dv[2];
+      zero16r(dk[0]);
+      zero16r(dk[1]);
+      zero16r(dv[0]);
+      zero16r(dv[1]);
+      for (int qb = 0; qb < nb; ++qb)
+        dkv_step(kf, vf, dk, dv, rpart, tpart, __builtin_amdgcn_readfirstlane(QO + qb * 4096), GO - QO, lse_s, dlt_s, sc2v, scv, qb * 32,
+                 p.N, qb == last && (p.N & 31), hi);
+      if (ri < p.N) {
+        const bool rot = p.rope_sin && ri >= p.rope_prefix;
+        store_acc_rows(p.dk + (long)b * p.sb + (long)ri * p.sn + h * 64, dk, hi, rot ? p.rope_sin : nullptr, p.rope_cos,
+                       (long)(ri - p.rope_prefix) * 64);
+        store_acc_rows(p.dv + (long)b * p.sb + (long)ri * p.sn + h * 64, dv, hi, nullptr, nullptr, 0);
+      }
+    }
+    if (odd) {  // the 9th block's keys against query block `wave` (wave 0: and against the 9th query block)
+      const int ox = __builtin_amdgcn_readfirstlane(PB_WAVES * 4096);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = frag_row_at(lds_addr(rpart[ks], KO + ox));
+        vf[ks] = frag_row_at(lds_addr(rpart[ks], VO + ox));
+      }
+      for (int qb = wave; qb < nb; qb += PB_WAVES) {
+        f32x16 dkx[2], dvx[2];
+        zero16r(dkx[0]);
+        zero16r(dkx[1]);
+        zero16r(dvx[0]);
+        zero16r(dvx[1]);
+        dkv_step(kf, vf, dkx, dvx, rpart, tpart, __builtin_amdgcn_readfirstlane(QO + qb * 4096), GO - QO, lse_s, dlt_s, sc2v, scv,
+                 qb * 32, p.N, qb == last && (p.N & 31), hi);
+        if ((lane & 31) < nx) {
+          put_slot(xk + (qb * PB_XROWS + (lane & 31)) * 64, dkx, hi);
+          put_slot(xv + (qb * PB_XROWS + (lane & 31)) * 64, dvx, hi);
+        }
+      }
+    }
+  }
+  if (odd) {
+    __syncthreads();
+    if ((int)threadIdx.x < nx * 8) {
+      const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), krow_i = 32 * PB_WAVES + row;
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hv = lo, c0 = lo, c1 = lo;
+      for (int qb = 0; qb < nb; ++qb) {
+        lo += *(const f32x4*)(xk + (qb * PB_XROWS + row) * 64 + d0);
+        hv += *(const f32x4*)(xk + (qb * PB_XROWS + row) * 64 + 32 + d0);
+        c0 += *(const f32x4*)(xv + (qb * PB_XROWS + row) * 64 + d0);
+        c1 += *(const f32x4*)(xv + (qb * PB_XROWS + row) * 64 + 32 + d0);
+      }
+      const bool rot = p.rope_sin && krow_i >= p.rope_prefix;
+      store_grad_pair(p.dk + (long)b * p.sb + (long)krow_i * p.sn + h * 64, d0, lo, hv, rot ? p.rope_sin : nullptr, p.rope_cos,
+                      (long)(krow_i - p.rope_prefix) * 64);
+      store_grad_pair(p.dv + (long)b * p.sb + (long)krow_i * p.sn + h * 64, d0, c0, c1, nullptr, nullptr, 0);
+    }
+  }
+  PB_STAMP(3);
 }
 
 // a head with >= 4 row blocks is split over two workgroups (each stages the whole K / V or Q / dO image, 2 x 37 KB at N = 257):
@@ -743,6 +1152,11 @@ template <typename K>
 static void set_lds(K kern, int bytes) {
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
+
+static long long* g_attn_timing = nullptr;
+static int g_attn_wpb = 0;      // diagnostics: > 0 per-head kernels with that many waves per workgroup, -1 per-head kernels, 0 default
+static int g_attn_lds_pad = 0;
+static int g_attn_stagger = 0;  // diagnostics: extra dynamic LDS bytes per backward workgroup (occupancy experiments)
 
 // host side, called by vtp_attn_fwd / vtp_attn_bwd (attention.hip) for non-causal N <= RES_MAXN
 int attn_resident_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int N, int heads, long sb,
@@ -796,17 +1210,50 @@ int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o
   a.lse = (float*)lse; a.delta = delta; a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv;
   a.rope_sin = (const bf16*)rope_sin; a.rope_cos = (const bf16*)rope_cos; a.rope_prefix = rope_prefix;
   a.B = B; a.N = N; a.heads = heads; a.npad = (N + 31) / 32 * 32; a.sb = sb; a.sn = sn; a.sbo = sbo; a.sno = sno; a.scale = scale;
+  a.timing = g_attn_timing;
+  a.stagger = g_attn_stagger;
   static bool attr = false;
   if (!attr) {
-    set_lds(attn_bwd_dq_res_kernel, 2 * RES_MAXN * 128);
-    set_lds(attn_bwd_dkv_res_kernel, 2 * RES_MAXN * 128 + 8 * RES_MAXN);
+    set_lds(attn_bwd_dq_res_kernel, 2 * RES_MAXN * 128 + 32768);  // (+ room for the diagnostic pad)
+    set_lds(attn_bwd_dkv_res_kernel, 2 * RES_MAXN * 128 + 8 * RES_MAXN + 32768);
     attr = true;
   }
-  const int nw = a.npad / 32, wpb = res_waves_per_block(nw, heads * B);
+  const int nw = a.npad / 32;
+  if (g_attn_wpb == 0 && (nw == PB_WAVES || (nw == PB_WAVES + 1 && N - 32 * PB_WAVES <= PB_XROWS))) {
+    // fused kernel: one workgroup of 8 waves per head, the four operand images in LDS
+    constexpr int PB_NPAD = 32 * (PB_WAVES + 1);
+    auto lds_of = [](int npad) { return 4 * npad * 128 + 8 * npad + 3 * 9 * PB_XROWS * 256; };
+    static bool attr_p = false;
+    if (!attr_p) {
+      set_lds(attn_bwd_fused_kernel, lds_of(PB_NPAD));
+      attr_p = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * heads), dim3(64 * PB_WAVES), lds_of(a.npad), s, a);
+    return check_launch("attn_bwd_fused");
+  }
+  const int wpb = g_attn_wpb > 0 ? std::min(g_attn_wpb, nw) : res_waves_per_block(nw, heads * B);
   const dim3 grid(heads, B, (nw + wpb - 1) / wpb), block(64 * wpb);
-  hipLaunchKernelGGL(attn_bwd_dq_res_kernel, grid, block, 2 * a.npad * 128, s, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, grid, block, 2 * a.npad * 128 + 8 * a.npad, s, a);
+  if (a.timing) {  // diagnosis only
+    int o1 = -1, o2 = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, attn_bwd_dq_res_kernel, block.x, 2 * a.npad * 128);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, attn_bwd_dkv_res_kernel, block.x, 2 * a.npad * 128 + 8 * a.npad);
+    fprintf(stderr, "[attn timing] workgroups per CU by the runtime's count: dQ %d, dK/dV %d (%d waves, lds %d / %d B)\n", o1, o2,
+            (int)block.x / 64, 2 * a.npad * 128, 2 * a.npad * 128 + 8 * a.npad);
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_res_kernel, grid, block, 2 * a.npad * 128 + g_attn_lds_pad, s, a);
+  if (a.timing) a.timing += (size_t)grid.x * grid.y * grid.z * 64;  // second half of the buffer: the dK / dV kernel
+  hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, grid, block, 2 * a.npad * 128 + 8 * a.npad + g_attn_lds_pad, s, a);
   return check_launch("attn_bwd_resident");
 }
 
 }  // namespace vtp
+
+// diagnostics (tools/attn_bwd_timeline.py): device buffer of 2 x [workgroups][16 waves][4] 64-bit s_memrealtime stamps written by
+// the resident backward kernels (dQ kernel first, dK/dV kernel behind it), or null = off.  Process-global.
+extern "C" int vtp_attn_debug(void* timing, int lds_pad, int waves_per_wg, int stagger_ticks) {
+  vtp::g_attn_stagger = stagger_ticks;
+  vtp::g_attn_wpb = waves_per_wg;
+  vtp::g_attn_timing = (long long*)timing;
+  vtp::g_attn_lds_pad = lds_pad;
+  return 0;
+}

@@ -396,18 +396,19 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
   }
 }
 
-// the 256x256 8-phase kernel (cfg 8, gemm8p.hip; one workgroup per CU) wins when its tile list fills whole rounds of the 256
-// CUs: measured on MI355X (tools/gemm8p_bench.py, profiles/r02_gemm8p_bench.log) at M = 34144 / 16448 / 8224 rows
+// the 256x256 8-phase kernel (cfg 8, gemm8p.hip; one workgroup per CU) against the ring kernels: measured on MI355X
+// (tools/gemm8p_bench.py, profiles/r03_gemm8p_bench.log) at M = 34144 / 16448 / 8224 rows.  With the round-3 epilogues (bias /
+// LayerScale / residual prefetch per tile, tile-local addressing) it wins or ties from ~96 tiles on -- also where its tile list
+// fills only 1.6 or 2.03 rounds of the CUs (fp32-residual K = 768 projection: x1.6 .. 1.7; w3 dgrad at 16448 rows: x1.4) -- except
+// the short-K bf16 shapes with ~100 tiles (x0.96)
 static bool use_8p_nt(int M, int N, int K, int epilogue) {
   if (N < 256 || K < 512) return false;
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
-  const int rounds = cdiv(tiles, 256);
-  const bool fills = tiles >= 192 && 4 * tiles >= 3 * rounds * 256;  // >= 75 % of the CU-rounds it occupies
   switch (epilogue) {
-    case VTP_EPI_F32: return fills && K >= 2048;  // fp32 residual epilogue: HBM-bound at K = 768, the ring kernels overlap it better
-    case VTP_EPI_SWIGLU: return fills || tiles >= 512;
+    case VTP_EPI_F32:
+    case VTP_EPI_SWIGLU: return tiles >= 96;
     case VTP_EPI_BF16:
-    case VTP_EPI_GELU: return fills;
+    case VTP_EPI_GELU: return tiles >= (K < 1024 ? 192 : 96);
     default: return false;
   }
 }

@@ -101,7 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
   // one).  An opaque copy of the lane id per tile keeps those values tile-local: recomputed with a few VALU, never spilled.
   // (not for the fp32-residual epilogue and the SwiGLU-backward variant: their own live sets -- residual / pre-activation
   // prefetch -- leave no room to recompute; measured slower with it)
-  if constexpr (EPI != EPI_F32 && XMODE != 2) asm volatile("" : "+v"(lane));
+  if constexpr (EPI != EPI_F32) asm volatile("" : "+v"(lane));
   const int hi = lane >> 5;
   const bool x_rope = XMODE < 0 ? p.rope_pos != nullptr : XMODE == 1;
   const bool x_swiglu = XMODE < 0 ? p.swiglu_pre != nullptr : XMODE == 2;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       staged_out = true;
       constexpr int RB = WTN * 2, CPR = RB / 16;
       static_assert(32 * RB <= REGION, "wave region too small for a 32-row block");
-      const int r = lane & 31;
+      const int lane_t = lane;
       constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
       // the lane's bias values do not depend on the row block: ONE round of loads per tile (in front of the first block's
       // conversions) instead of one L2 round trip inside every block
@@ -130,20 +130,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             bias_v[i][q] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
       }
+      // fused SwiGLU backward: the x1 | x2 pre-activations of row block j + 1 are requested before block j is transposed, converted
+      // and stored (two register sets): the epilogue is bound by the bytes a CU keeps in flight, not by HBM -- with one block's loads
+      // issued behind the previous block's stores every block paid a full load round trip (25 us per tile, 11 B/clk per CU)
+      bf16x8 sx1[2][TPB], sx2[2][TPB];
+      auto fetch_pre = [&](int j, bf16x8 (&d1)[TPB], bf16x8 (&d2)[TPB]) {
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+          const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+          const int m = min(m0 + wm * WTM + j * 32 + rr, p.M - 1), n = min(n0 + wn * WTN + c * 8, p.N - 8);
+          const bf16* xr = p.swiglu_pre + (size_t)m * p.swiglu_ld + 2 * n;
+          d1[t] = *(const bf16x8*)xr;
+          d2[t] = *(const bf16x8*)(xr + 8);
+        }
+      };
+      if (x_swiglu) fetch_pre(0, sx1[0], sx2[0]);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        // fused SwiGLU backward: this block's x1 | x2 pre-activations are requested BEFORE the accumulators go through LDS, so the
-        // loads fly while the block is transposed (they are consumed in the store loop below)
-        bf16x8 sx1[TPB], sx2[TPB];
-        if (x_swiglu) {
-#pragma unroll
-          for (int t = 0; t < TPB; ++t) {
-            const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
-            const int m = min(m0 + wm * WTM + j * 32 + rr, p.M - 1), n = min(n0 + wn * WTN + c * 8, p.N - 8);
-            const bf16* xr = p.swiglu_pre + (size_t)m * p.swiglu_ld + 2 * n;
-            sx1[t] = *(const bf16x8*)xr;
-            sx2[t] = *(const bf16x8*)(xr + 8);
-          }
+        if (x_swiglu && j + 1 < TM) fetch_pre(j + 1, sx1[(j + 1) & 1], sx2[(j + 1) & 1]);
+        // (per row block again an opaque lane id: the LDS / global addressing of the four unrolled blocks is otherwise shared, lives
+        // across the whole epilogue and spills -- with a drain of every load in flight behind each reload)
+        int lane = lane_t, hi = lane_t >> 5, r = lane_t & 31;
+        if constexpr (XMODE == 2) {
+          asm volatile("" : "+v"(lane));
+          hi = lane >> 5;
+          r = lane & 31;
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -182,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           }
           if (x_swiglu) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
             if (m < p.M && n < p.N) {
-              const bf16x8 x1 = sx1[t], x2 = sx2[t];
+              const bf16x8 x1 = sx1[j & 1][t], x2 = sx2[j & 1][t];
               bf16x8 o1, o2;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
