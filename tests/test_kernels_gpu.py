@@ -342,14 +342,18 @@ def test_prep_weights_casts_and_interleave():
     w12T = torch.empty(D, 2 * H, dtype=torch.bfloat16, device=DEV)
     b12 = torch.empty(2 * H, device=DEV)
     rows, tiles = [], 0
+    wo = torch.randn(203, 134, device=DEV, generator=g)  # odd shape: the scalar path of the kernel
+    wob = torch.empty(203, 134, dtype=torch.bfloat16, device=DEV)
+    woT = torch.empty(134, 203, dtype=torch.bfloat16, device=DEV)
     for src, src2, dst, dstT, R, C, mode in [(w, None, wb, wT, 200, 136, 0), (w1, w2, w12, w12T, 2 * H, D, 1),
-                                             (b1, b2, b12, None, 2 * H, 1, 2)]:
+                                             (b1, b2, b12, None, 2 * H, 1, 2), (wo, None, wob, woT, 203, 134, 0)]:
         rows.append([src.data_ptr(), src2.data_ptr() if src2 is not None else 0, dst.data_ptr(),
                      dstT.data_ptr() if dstT is not None else 0, R, C, mode, tiles])
         tiles += (R + 255) // 256 if mode == 2 else ((R + 63) // 64) * ((C + 63) // 64)
     desc = torch.tensor(rows, dtype=torch.int64, device=DEV)
     o.prep_weights(desc, len(rows), tiles)
     assert torch.equal(wb, bf(w)) and torch.equal(wT, bf(w).T)
+    assert torch.equal(wob, bf(wo)) and torch.equal(woT, bf(wo).T)
     assert torch.equal(w12, bf(interleave(w1, w2))) and torch.equal(w12T, bf(interleave(w1, w2)).T)
     assert torch.equal(b12, interleave(b1, b2))
     out = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
