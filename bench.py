@@ -501,12 +501,12 @@ def main():
                     fh.write(f"{key[0]:14s} M={key[1]:6d} N={key[2]:6d} K={key[3]:6d} epi={key[4]} splits={key[5]:2d}  calls={n:3d}  "
                              f"total={t:7.3f} ms  avg={t / n * 1e3:7.1f} us  {f / t / 1e9:7.1f} TF/s\n")
         traffic, traffic_src = None, None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (2, 1)) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
         if pmc and args.workload == "vtp_base_full" and not args.batch:
             try:  # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes of this command
                 d = json.load(open(pmc))
                 by, n = 0.0, 0
-                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn"):
+                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn"):
                     if fam not in d:
                         continue
                     # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2, MI355X_MICROARCH.md HBM)

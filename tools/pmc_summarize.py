@@ -11,11 +11,13 @@ from collections import defaultdict
 def family(name: str) -> str:
     name = re.sub(r"^void ", "", name)
     m = re.match(r"(?:vtp::)?(\w+)", name.replace("_ZN3vtp", ""))
+    if "gemm8p_grouped_tn_kernel" in name:
+        return "gemm8p_grouped_tn"
     if "gemm8p_kernel" in name:
         return "gemm8p_tn" if re.search(r"gemm8p_kernel<\d+, true", name) else "gemm8p_nt"
     if "gemm_nt_kernel" in name:
         return "gemm_tn" if re.search(r"gemm_nt_kernel<[^>]*, true, (true|false)>", name) else "gemm_nt"
-    for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "norm_bwd", "norm_fwd", "adamw", "prep_weights", "colsum_bf16",
+    for k in ("attn_fwd", "attn_bwd_fused", "attn_bwd_dq", "attn_bwd_dkv", "norm_bwd", "norm_fwd", "adamw", "prep_weights", "colsum_bf16",
               "reduce_slabs", "swiglu_bwd", "rope_qk", "softmax_center", "dino_ce", "ema_kernel"):
         if k in name:
             return k

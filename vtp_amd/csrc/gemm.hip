@@ -402,8 +402,11 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
 // fills only 1.6 or 2.03 rounds of the CUs (fp32-residual K = 768 projection: x1.6 .. 1.7; w3 dgrad at 16448 rows: x1.4) -- except
 // the short-K bf16 shapes with ~100 tiles (x0.96)
 static bool use_8p_nt(int M, int N, int K, int epilogue) {
-  if (N < 256 || K < 512) return false;
+  if (N < 256 || K < 256) return false;
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
+  // K = 256 with thousands of tiles (the DINO head's prototype logits: 2816 x 65536, four k-tiles per tile): all epilogue -- the
+  // LDS-staged full-line stores of the 8-phase kernel run it at 157 us, the ring kernels' 256 x 256 configuration at 525 us
+  if (K < 512) return epilogue == VTP_EPI_BF16 && tiles >= 1024;
   switch (epilogue) {
     case VTP_EPI_F32:
     case VTP_EPI_SWIGLU: return tiles >= 96;
