@@ -220,7 +220,9 @@ def _attn_ref(q, k, v, causal):
                                               (16, 37, 12, False), (96, 257, 12, False),
                                               # persistent backward kernels: two rows in the odd 9th block, several heads per
                                               # workgroup at 8 row blocks, the last block partly filled
-                                              (3, 258, 2, False), (40, 256, 8, False), (2, 230, 2, False)])
+                                              (3, 258, 2, False), (40, 256, 8, False), (2, 230, 2, False),
+                                              # ... and its two-wave instantiation (33 .. 66 tokens)
+                                              (4, 64, 2, False), (2, 66, 3, False), (5, 40, 2, False)])
 def test_attention_fwd_bwd(B, N, heads, causal):
     o = ops()
     D = heads * 64

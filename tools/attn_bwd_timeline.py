@@ -50,7 +50,7 @@ def run(lib, B, N, h):
     if WPB > 0:
         wpb = min(WPB, nblk)
     nwg = B * h * ((nblk + wpb - 1) // wpb)
-    if WPB == 0 and (nblk == 8 or (nblk == 9 and N - 256 <= 2)):  # persistent kernels: one record per head
+    if WPB == 0 and (nblk in (8, 2) or (nblk == 9 and N - 256 <= 2) or (nblk == 3 and N - 64 <= 2)):  # fused kernel: one workgroup per head
         nwg = B * h
     tbuf = torch.zeros(2 * nwg_max * 64, dtype=torch.int64, device=dev)
     lib.vtp_attn_debug(tbuf.data_ptr(), PAD, WPB, STAG)
@@ -62,7 +62,7 @@ def run(lib, B, N, h):
     lib.vtp_attn_debug(None, 0, 0, 0)
     print(f"== B={B} N={N} heads={h}: backward {e0.elapsed_time(e1) * 1e3:.1f} us (both kernels, stamped run)")
     t = tbuf.cpu().double() / 100.0  # us
-    fused = WPB == 0 and (nblk == 8 or (nblk == 9 and N - 256 <= 2))
+    fused = WPB == 0 and (nblk in (8, 2) or (nblk == 9 and N - 256 <= 2) or (nblk == 3 and N - 64 <= 2))
     for ki, name in enumerate(("fused",) if fused else ("dQ", "dK/dV")):
         seg = t[ki * nwg * 64:(ki + 1) * nwg * 64].view(nwg, 16, 4)
         act = seg[:, :, 1] > 0

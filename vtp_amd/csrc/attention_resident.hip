@@ -821,9 +821,10 @@ __global__ __launch_bounds__(640) void attn_bwd_dkv_res_kernel(const AttnResArgs
 constexpr int PB_WAVES = 8;
 constexpr int PB_XROWS = 2;  // rows of the odd 9th block (N - 256 <= 2)
 
-__device__ __forceinline__ int stage_image_asm(const bf16* base, long sn, int N, int npad, unsigned img_off, int wave, int lane) {
+__device__ __forceinline__ int stage_image_asm(const bf16* base, long sn, int N, int npad, unsigned img_off, int wave, int nwaves,
+                                               int lane) {
   int n = 0;
-  for (int piece = wave; piece < (npad >> 3); piece += PB_WAVES, ++n) stage_piece_asm(base, sn, N, piece, img_off, lane);
+  for (int piece = wave; piece < (npad >> 3); piece += nwaves, ++n) stage_piece_asm(base, sn, N, piece, img_off, lane);
   return n;
 }
 
@@ -954,25 +955,27 @@ __device__ __forceinline__ void store_acc_rows(bf16* row, const f32x16 (&acc)[2]
   }
 }
 
-__global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const AttnResArgs p) {
+// W = waves = full row blocks per head: 8 (N = 225 .. 258) or 2 (N = 33 .. 66: the 37-token local crops, four workgroups per CU)
+template <int W>
+__global__ __launch_bounds__(64 * W) void attn_bwd_fused_kernel(const AttnResArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
   const int img = p.npad * 128, nb = p.npad >> 5, last = nb - 1;
-  const bool odd = nb > PB_WAVES;
-  const int nx = odd ? p.N - 32 * PB_WAVES : 0;  // valid rows of the 9th block
+  const bool odd = nb > W;
+  const int nx = odd ? p.N - 32 * W : 0;  // valid rows of the 9th block
   // LDS: Q | K | V | dO images, then -lse log2(e) and -delta scale per query, then the slots of the 9th block's dq, dk, dv rows
   const int QO = 0, KO = img, VO = 2 * img, GO = 3 * img;
   float* lse_s = (float*)(smem + 4 * img);
   float* dlt_s = lse_s + p.npad;
-  float* xq = dlt_s + p.npad;           // [9][PB_XROWS][64]
-  float* xk = xq + 9 * PB_XROWS * 64;
-  float* xv = xk + 9 * PB_XROWS * 64;
+  float* xq = dlt_s + p.npad;           // [W + 1][PB_XROWS][64]
+  float* xk = xq + (W + 1) * PB_XROWS * 64;
+  float* xv = xk + (W + 1) * PB_XROWS * 64;
   const int hid = blockIdx.x, b = hid / p.heads, h = hid - b * p.heads;
   PB_STAMP(0);
-  stage_image_asm(p.q + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, QO, wave, lane);
-  stage_image_asm(p.d_o + (long)b * p.sbo + h * 64, p.sno, p.N, p.npad, GO, wave, lane);
-  stage_image_asm(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, KO, wave, lane);
-  stage_image_asm(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, VO, wave, lane);
+  stage_image_asm(p.q + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, QO, wave, W, lane);
+  stage_image_asm(p.d_o + (long)b * p.sbo + h * 64, p.sno, p.N, p.npad, GO, wave, W, lane);
+  stage_image_asm(p.k + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, KO, wave, W, lane);
+  stage_image_asm(p.v + (long)b * p.sb + h * 64, p.sn, p.N, p.npad, VO, wave, W, lane);
   const float sc2 = p.scale * LOG2E_R;
   const f32x2 sc2v = {sc2, sc2}, scv = {p.scale, p.scale};
   int rpart[4], tpart[2][2];
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
     for (int hf = 0; hf < 2; ++hf) tpart[db][hf] = tr_part(lane, hf) ^ (db << 6);
   const long srow0 = ((long)b * p.heads + h) * p.N;
   const int ri = wave * 32 + (lane & 31);                     // this lane's row of block `wave` (query in phase 1, key in phase 2)
-  const int rx = 32 * PB_WAVES + (lane & 31);                 // ... and of the 9th block
+  const int rx = 32 * W + (lane & 31);                 // ... and of the 9th block
   // O rows and lse of this lane's queries (the only per-lane global loads left)
   bf16x8 of[4], of2[4];
   float lse_raw, lse_raw2 = 0.f;
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
       }
     }
     if (odd) {  // the 9th block's queries against key block `wave` (wave 0: and against the 9th key block)
-      const int ox = __builtin_amdgcn_readfirstlane(PB_WAVES * 4096);
+      const int ox = __builtin_amdgcn_readfirstlane(W * 4096);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         qf[ks] = frag_row_at(lds_addr(rpart[ks], QO + ox));
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
       }
       const float lse2 = lse_raw2 * LOG2E_R;
       const f32x2 nlse = {-lse2, -lse2}, ndlt = {-dlt2 * p.scale, -dlt2 * p.scale};
-      for (int kb = wave; kb < nb; kb += PB_WAVES) {
+      for (int kb = wave; kb < nb; kb += W) {
         f32x16 dqx[2];
         zero16r(dqx[0]);
         zero16r(dqx[1]);
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
   __syncthreads();  // lse_s / dlt_s and the 9th block's dq slots are complete
   PB_STAMP(2);
   if (odd && (int)threadIdx.x < nx * 8) {
-    const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), qrow = 32 * PB_WAVES + row;
+    const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), qrow = 32 * W + row;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
     for (int kb = 0; kb < nb; ++kb) {
       lo += *(const f32x4*)(xq + (kb * PB_XROWS + row) * 64 + d0);
@@ -1099,13 +1102,13 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
       }
     }
     if (odd) {  // the 9th block's keys against query block `wave` (wave 0: and against the 9th query block)
-      const int ox = __builtin_amdgcn_readfirstlane(PB_WAVES * 4096);
+      const int ox = __builtin_amdgcn_readfirstlane(W * 4096);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         kf[ks] = frag_row_at(lds_addr(rpart[ks], KO + ox));
         vf[ks] = frag_row_at(lds_addr(rpart[ks], VO + ox));
       }
-      for (int qb = wave; qb < nb; qb += PB_WAVES) {
+      for (int qb = wave; qb < nb; qb += W) {
         f32x16 dkx[2], dvx[2];
         zero16r(dkx[0]);
         zero16r(dkx[1]);
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(64 * PB_WAVES) void attn_bwd_fused_kernel(const Att
   if (odd) {
     __syncthreads();
     if ((int)threadIdx.x < nx * 8) {
-      const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), krow_i = 32 * PB_WAVES + row;
+      const int row = threadIdx.x >> 3, d0 = 4 * (threadIdx.x & 7), krow_i = 32 * W + row;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hv = lo, c0 = lo, c1 = lo;
       for (int qb = 0; qb < nb; ++qb) {
         lo += *(const f32x4*)(xk + (qb * PB_XROWS + row) * 64 + d0);
@@ -1219,16 +1222,20 @@ int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o
     attr = true;
   }
   const int nw = a.npad / 32;
-  if (g_attn_wpb == 0 && (nw == PB_WAVES || (nw == PB_WAVES + 1 && N - 32 * PB_WAVES <= PB_XROWS))) {
-    // fused kernel: one workgroup of 8 waves per head, the four operand images in LDS
-    constexpr int PB_NPAD = 32 * (PB_WAVES + 1);
-    auto lds_of = [](int npad) { return 4 * npad * 128 + 8 * npad + 3 * 9 * PB_XROWS * 256; };
+  auto fits = [&](int W) { return nw == W || (nw == W + 1 && N - 32 * W <= PB_XROWS); };
+  if (g_attn_wpb == 0 && (fits(PB_WAVES) || fits(2))) {
+    // fused kernel: one workgroup of W waves per head, the four operand images in LDS
+    auto lds_of = [](int npad, int W) { return 4 * npad * 128 + 8 * npad + 3 * (W + 1) * PB_XROWS * 256; };
     static bool attr_p = false;
     if (!attr_p) {
-      set_lds(attn_bwd_fused_kernel, lds_of(PB_NPAD));
+      set_lds(attn_bwd_fused_kernel<PB_WAVES>, lds_of(32 * (PB_WAVES + 1), PB_WAVES));
+      set_lds(attn_bwd_fused_kernel<2>, lds_of(32 * 3, 2));
       attr_p = true;
     }
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(B * heads), dim3(64 * PB_WAVES), lds_of(a.npad), s, a);
+    if (fits(PB_WAVES))
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<PB_WAVES>, dim3(B * heads), dim3(64 * PB_WAVES), lds_of(a.npad, PB_WAVES), s, a);
+    else
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(B * heads), dim3(128), lds_of(a.npad, 2), s, a);
     return check_launch("attn_bwd_fused");
   }
   const int wpb = g_attn_wpb > 0 ? std::min(g_attn_wpb, nw) : res_waves_per_block(nw, heads * B);

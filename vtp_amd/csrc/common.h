@@ -67,6 +67,32 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // by one bf16 ulp -- inside the per-kernel parity bar, tests/test_kernels_gpu.py).
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// SwiGLU backward of 8 elements (ffn.py:78-81 under bf16 autocast): x1 | x2 pre-activations, dh the gradient of silu(x1) x2
+//   -> o1 = d/dx1, o2 = d/dx2 with the roundings of eager bf16 autograd (gs = bf16(dh x2), silu(x1) rounded to bf16 before the
+//   product with dh).  Written on fp32 PAIRS: v_pk_mul / v_pk_add / v_pk_fma carry two elements per instruction -- the fused
+//   w3-dgrad epilogue is bound by exactly this VALU work (2 781 instructions per wave and 256x256 tile with the scalar form).
+//   The standalone kernels and the GEMM epilogue share this function, so they stay bit-identical (tests/test_kernels_gpu.py).
+__device__ __forceinline__ void swiglu_bwd8(const bf16x8& x1, const bf16x8& x2, const bf16x8& dh, bf16x8& o1, bf16x8& o2) {
+  const f32x2 one = {1.f, 1.f}, nl2e = {-1.4426950408889634f, -1.4426950408889634f};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 a = {bf2f(x1[e]), bf2f(x1[e + 1])}, b = {bf2f(x2[e]), bf2f(x2[e + 1])}, gd = {bf2f(dh[e]), bf2f(dh[e + 1])};
+    const f32x2 t = a * nl2e;
+    const f32x2 den = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + one;
+    const f32x2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};  // sigmoid(x1)
+    const bf16x2 gsb = __builtin_convertvector(gd * b, bf16x2);                          // grad wrt silu(x1), bf16 like autograd
+    const f32x2 gs = {bf2f(gsb[0]), bf2f(gsb[1])};
+    const f32x2 dsilu = sg * __builtin_elementwise_fma(a, one - sg, one);                // silu'(x1) = sg (1 + x1 (1 - sg))
+    const bf16x2 r1 = __builtin_convertvector(gs * dsilu, bf16x2);
+    const bf16x2 sb = __builtin_convertvector(a * sg, bf16x2);                           // silu(x1) rounded to bf16
+    const bf16x2 r2 = __builtin_convertvector(gd * f32x2{bf2f(sb[0]), bf2f(sb[1])}, bf16x2);
+    o1[e] = r1[0];
+    o1[e + 1] = r1[1];
+    o2[e] = r2[0];
+    o2[e + 1] = r2[1];
+  }
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

@@ -347,14 +347,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict_
     bf16x8 x1 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g);
     bf16x8 x2 = *(const bf16x8*)(x12 + m * 2L * H + 16 * g + 8);
     bf16x8 o1, o2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = bf2f(x1[e]), b = bf2f(x2[e]), gd = bf2f(d[e]);
-      const float sg = sigmoid_f(a);
-      const float gs = bf2f(f2bf(gd * b));                  // grad wrt silu(x1) (bf16 like eager autograd)
-      o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));    // silu'
-      o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));               // grad wrt x2 = dh * silu(x1)
-    }
+    swiglu_bwd8(x1, x2, d, o1, o2);
     *(bf16x8*)(dx12 + m * 2L * H + 16 * g) = o1;
     *(bf16x8*)(dx12 + m * 2L * H + 16 * g + 8) = o2;
   }
@@ -389,13 +382,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_rows_kernel(const bf16* __rest
         const long m = m0 + r * step;
         if (m >= M) break;
         bf16x8 o1, o2;
+        swiglu_bwd8(x1[r], x2[r], d[r], o1, o2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = bf2f(x1[r][e]), b = bf2f(x2[r][e]), gd = bf2f(d[r][e]);
-          const float sg = sigmoid_f(a);
-          const float gs = bf2f(f2bf(gd * b));                  // grad wrt silu(x1) (bf16 like eager autograd)
-          o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));    // silu'
-          o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));               // grad wrt x2 = dh * silu(x1)
           s1[e] += bf2f(o1[e]);
           s2[e] += bf2f(o2[e]);
         }

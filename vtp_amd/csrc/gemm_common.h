@@ -193,16 +193,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           }
           if (x_swiglu) {  // wave-uniform: val = dh of one 8-column group -> dx1 | dx2 (same roundings as swiglu_bwd_kernel)
             if (m < p.M && n < p.N) {
-              const bf16x8 x1 = sx1[j & 1][t], x2 = sx2[j & 1][t];
               bf16x8 o1, o2;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float a = bf2f(x1[e]), b = bf2f(x2[e]), gd = bf2f(val[e]);
-                const float sg = sigmoid_f(a);
-                const float gs = bf2f(f2bf(gd * b));
-                o1[e] = f2bf(gs * (sg * (1.f + a * (1.f - sg))));
-                o2[e] = f2bf(gd * bf2f(f2bf(a * sg)));
-              }
+              swiglu_bwd8(sx1[j & 1][t], sx2[j & 1][t], val, o1, o2);
               bf16* orow = (bf16*)p.C + (size_t)m * p.ldc + 2 * n;
               *(bf16x8*)orow = o1;
               *(bf16x8*)(orow + 8) = o2;
