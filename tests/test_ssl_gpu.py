@@ -175,12 +175,12 @@ def test_ssl_forward_vs_reference_legacy_class(sslg):
     for k in ("teacher_cls_tokens_after_head", "masked_teacher_patch_tokens_after_head"):
         e, e_ref = relF(t_out[k], g["teacher." + k]), relF(t_b[k], g["teacher." + k])
         print(f"teacher {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
-        assert e <= max(1.5 * e_ref, 1e-2), k
+        assert e <= (1.5 * e_ref), k
     for k in ("student_local_cls_tokens_after_head", "student_global_cls_tokens_after_head", "student_global_cls_tokens",
               "student_global_masked_patch_tokens_after_head"):
         e, e_ref = relF(s_out[k], g["student." + k]), relF(s_b[k], g["student." + k])
         print(f"student {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
-        assert e <= max(1.5 * e_ref, 1e-2), k
+        assert e <= (1.5 * e_ref), k
     assert t_out["n_masked_patches"] == int(idx.numel())
 
 
@@ -214,7 +214,7 @@ def test_ssl_step_gradients_vs_reference_autograd(sslg):
         ref = g["grad." + k]
         e, e_ref = relF(params[k].grad, ref), relF(sdr[k].grad, ref)
         print(f"ssl grad {k}: E_ours={e:.3e} E_ref={e_ref:.3e}")
-        assert e <= max(1.5 * e_ref, 3e-2) and e < 0.1, k
+        assert e <= (1.5 * e_ref) and e < 0.1, k
     # centre update: c = 0.9 c + 0.1 mean(teacher logits)
     tc = g["teacher.teacher_cls_tokens_after_head"]
     ref_c = 0.9 * g["in.center_dino"] + 0.1 * tc.mean(0)
