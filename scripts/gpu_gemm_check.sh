@@ -1,4 +1,5 @@
 #!/bin/bash
+# GEMM regression check: kernel tests, the 8-phase timeline of the fp32-residual shape, the in-situ per-shape table of the step
 export PYTHONDONTWRITEBYTECODE=1
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gemm8p_gpu.py tests/test_kernels_gpu.py tests/test_fp8_gpu.py tests/test_model_gpu.py -x -q -p no:cacheprovider 2>&1 | tail -3
