@@ -478,10 +478,15 @@ def main():
     trainer.use_graphs = False   # events cannot sit inside a replayed graph: this step launches eagerly
     overlap_was = eng.OVERLAP.enabled
     eng.OVERLAP.enabled = False  # per-kernel durations: no second stream sharing the CUs while a GEMM is timed
+    # (without the side streams the step announces its gradient buckets in finer pieces; the rank-sharded optimizer ties chunk
+    # ownership to the bucket layout and refuses a changed one -- this one untimed step after the measurement may re-assign it)
+    shard_layout_was = getattr(trainer, "_shard_layout", None)
+    trainer._shard_layout = None
     try:
         trainer.step(img, txt, ssl)  # every rank takes the step (it contains the collectives); rank 0 times its GEMMs
         torch.cuda.synchronize()
     finally:
+        trainer._shard_layout = shard_layout_was
         ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = orig_nt, orig_tn, orig_qkv, orig_dsw
         ops.WgradGroup.launch = orig_grp
         eng.OVERLAP.enabled = overlap_was
