@@ -84,12 +84,19 @@ class GradBucketer:
         """Launch (async) the sum-reduce-scatter of flat_g[lo:hi]: rank r receives chunk r in rec.g_out."""
         rec = self._rec(lo, hi)
         n = hi - lo
-        if self.grad_dtype == torch.float32:
+        # fp32 bucket that divides into `world` whole chunks (no padding) on RCCL: reduce-scatter straight out of the flat gradient
+        # buffer -- no staging copy (nothing writes this range again before the optimizer: its gradients are complete)
+        direct = self.grad_dtype == torch.float32 and n == rec.chunk * self.world and self.native()
+        if direct:
+            src = self.flat_g[lo:hi]
+        elif self.grad_dtype == torch.float32:
             rec.send[:n].copy_(self.flat_g[lo:hi])
+            src = rec.send
         else:
             ops.cast_f32_bf16(self.flat_g[lo:hi], rec.send, n)
+            src = rec.send
         if self.native():
-            w = self.dist.reduce_scatter_tensor(rec.g_out, rec.send, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = self.dist.reduce_scatter_tensor(rec.g_out, src, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.works.append((w, None))
         else:  # gloo has no reduce-scatter (and no bf16 on device tensors): all-reduce in fp32, keep the own chunk
             tmp = rec.send.float()
