@@ -271,6 +271,38 @@ def test_attention_fwd_bwd(B, N, heads, causal):
         assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
 
 
+@pytest.mark.parametrize("B,N,heads,prefix", [(3, 256, 2, 0), (2, 257, 3, 1), (6, 37, 2, 1), (2, 64, 2, 0), (2, 1025, 2, 1)])
+def test_attention_bwd_fused_inverse_rope_prefixes(B, N, heads, prefix):
+    """the inverse RoPE in the stores of the (fused) backward kernels with and without a cls prefix (the pixel decoder has none):
+    bit-identical to vtp_rope_qk(inverse) applied to the plain backward result"""
+    o = ops()
+    D = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(100 + N + prefix)
+    qkv = bf(torch.randn(B * N, 3 * D, device=DEV, generator=g))
+    out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, N, device=DEV)
+    o.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, lse, B, N, heads, N * 3 * D, 3 * D, N * D, D, 0.125, False)
+    d_o = bf(torch.randn(B * N, D, device=DEV, generator=g))
+    delta = torch.empty(B, heads, N, device=DEV)
+    plain = torch.full((B * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    o.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, d_o, lse, delta, plain, plain[:, D:], plain[:, 2 * D:], B, N, heads,
+               N * 3 * D, 3 * D, N * D, D, 0.125, False)
+    assert torch.isfinite(plain.float()).all()
+    sin = bf(torch.randn(N - prefix, 64, device=DEV, generator=g))
+    cos = bf(torch.randn(N - prefix, 64, device=DEV, generator=g))
+    want = plain.clone()
+    o.rope_qk(want, sin, cos, B, N, heads, prefix, inverse=True)
+    got = torch.full_like(plain, float("nan"))
+    o.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, d_o, lse, delta, got, got[:, D:], got[:, 2 * D:], B, N, heads,
+               N * 3 * D, 3 * D, N * D, D, 0.125, False, rope=(sin, cos), rope_prefix=prefix)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # a second launch gives the same bits (the odd block's partial sums are added in a fixed order)
+    again = torch.full_like(plain, float("nan"))
+    o.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, d_o, lse, delta, again, again[:, D:], again[:, 2 * D:], B, N, heads,
+               N * 3 * D, 3 * D, N * D, D, 0.125, False, rope=(sin, cos), rope_prefix=prefix)
+    assert torch.equal(again, got)
+
+
 # ----------------------------------------------------------------------------------------------------------- data movement
 def test_im2col_pixelshuffle_l1():
     o = ops()
