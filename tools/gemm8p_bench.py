@@ -44,9 +44,7 @@ def timeit(fns, rounds=7, iters=10):
 
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] in ("quick", "var")
-    var = len(sys.argv) > 1 and sys.argv[1] == "var"   # schedule-variant sweep (VTP_GEMM8P_VAR): bf16-output NT + slab TN only
-    if var:
-        print(f"VTP_GEMM8P_VAR={os.environ.get('VTP_GEMM8P_VAR', '0')}", flush=True)
+    var = len(sys.argv) > 1 and sys.argv[1] == "var"   # bf16-output NT + slab TN only
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)

@@ -10,8 +10,9 @@
 // disjoint bank quarters.  The image is filled by LDS-DMA (global_load_lds_dwordx4), the swizzle applied on the source side.
 //
 // Forward: attn_fwd_res2_kernel (default: two query tiles per wave, single-pass online softmax, K / V streamed behind the key
-// loop, odd last tile split over the waves); attn_fwd_res_kernel is the round-1 two-pass variant (VTP_ATTN_V2=0, and shapes the
-// v2 work split does not cover).  Backward: dQ and dK/dV kernels with delta and the inverse RoPE fused.
+// loop, odd last tile split over the waves); attn_fwd_res_kernel is the round-1 two-pass variant (shapes the
+// v2 work split does not cover).  Backward: one fused kernel at 33 .. 66 and 225 .. 258 tokens (attn_bwd_fused_kernel: the shapes of the
+// step), dQ and dK/dV kernels otherwise; delta and the inverse RoPE are fused in both.
 #include "common.h"
 #include <algorithm>
 #include <cstdio>

@@ -269,9 +269,9 @@ FUSE_SWIGLU_BWD = True
 FUSE_ROPE = True
 # the four weight gradients of a transformer block as ONE grouped launch with the split-K combine and the bias-gradient column
 # sums inside it (ops.WgradGroup), issued one block late so that it runs beside the NEXT block's dgrad / attention kernels
-# (VTP_WGRAD_GROUPED=0: the per-layer path -- one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that
-# layer's dgrad -- which LayerScale, stochastic depth and tiny token counts use anyway)
-WGRAD_GROUPED = _env_flag("VTP_WGRAD_GROUPED")
+# (the per-layer path -- one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that layer's dgrad -- is what
+# LayerScale, stochastic depth and tiny token counts use)
+WGRAD_GROUPED = True
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
