@@ -27,13 +27,14 @@ for M, N, K, epi in SHAPES:
         c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         kw = dict(bias=bias)
     res = {}
-    for cfg in (-1, 8):
+    CFGS = tuple(int(v) for v in os.environ.get("CFGS", "-1,8").split(","))
+    for cfg in CFGS:
         lib.vtp_set_gemm_tuning(cfg, 3)
         for _ in range(3):
             ops.gemm_nt(a, b, c, M=M, N=N, K=K, epi=epi, **kw)
         res[cfg] = []
     for _ in range(7):
-        for cfg in (-1, 8):
+        for cfg in CFGS:
             lib.vtp_set_gemm_tuning(cfg, 3)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -44,4 +45,4 @@ for M, N, K, epi in SHAPES:
             res[cfg].append(e0.elapsed_time(e1) * 100.0)
     lib.vtp_set_gemm_tuning(-1, 3)
     m = {k: sorted(v)[3] for k, v in res.items()}
-    print(f"M={M} N={N} K={K} epi={epi}: auto {m[-1]:6.1f} us | 8p {m[8]:6.1f} us  x{m[-1] / m[8]:.2f}", flush=True)
+    print(f"M={M} N={N} K={K} epi={epi}: " + " | ".join(f"cfg {c}: {m[c]:6.1f} us" for c in CFGS), flush=True)

@@ -388,6 +388,7 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
       case 4: return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, splits, s);
       case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, false>(a, splits, s);
       case 6: return launch_cfg<128, 128, 2, 2, 4, EPI, false>(a, splits, s);
+      case 7: return launch_cfg<128, 64, 4, 1, 3, EPI, false>(a, splits, s);   // few-tile shapes: twice the workgroups
       case 16: return launch_cfg<128, 128, 2, 2, 2, EPI, false, true>(a, splits, s);
       case 18: return launch_cfg<256, 128, 4, 2, 2, EPI, false, true>(a, splits, s);
       case 21: return launch_cfg<128, 128, 4, 2, 2, EPI, false, true>(a, splits, s);
@@ -442,6 +443,10 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   // big-M GEMMs (the row-concatenated list forward, M = 34k): 256x256 tiles halve the LDS / L2 traffic per flop; they
   // need >= 1.5 resident waves of tiles to beat the 128x128 kernels' finer quantisation (tools/gemm_bench.py 34144)
   if (cdiv(M, 256) * cdiv(N, 256) >= 384 && (N >= 2304 || K >= (epilogue == VTP_EPI_F32 ? 4096 : 2048))) return 4;
+  // few tiles (text tower M = 2464, DINO head M = 2816: 120 .. 360 tiles of 128 x 128 on 256 CUs): 128 x 64 tiles, 4 x 1 waves, three
+  // stages -- twice the workgroups, three of them per CU (tools/text_gemm_ab.py: N = 768, K = 3072 fp32-residual 50.3 -> 30.0 us,
+  // bf16 36.1 -> 28.1 us; not the GELU epilogue: 35.0 -> 38.7 us)
+  if ((epilogue == VTP_EPI_BF16 || epilogue == VTP_EPI_F32) && K >= 512 && cdiv(M, 128) * cdiv(N, 128) < 400) return 7;
   if (K >= 4096) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
