@@ -13,6 +13,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 SHAPES = [(2464, 3072, 768, ops.EPI_GELU), (2464, 3072, 768, ops.EPI_BF16), (2464, 2304, 768, ops.EPI_BF16), (2464, 768, 3072, ops.EPI_F32),
           (2464, 768, 3072, ops.EPI_BF16), (2464, 768, 2304, ops.EPI_BF16), (2464, 768, 768, ops.EPI_F32), (2464, 768, 768, ops.EPI_BF16),
           (2816, 2048, 2048, ops.EPI_GELU), (2816, 2048, 2048, ops.EPI_BF16), (2816, 2048, 768, ops.EPI_GELU), (2816, 256, 2048, ops.EPI_F32)]
+if os.environ.get("SHAPES"):  # "M,N,K,epi;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for M, N, K, epi in SHAPES:
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)

@@ -409,7 +409,7 @@ static bool use_8p_nt(int M, int N, int K, int epilogue) {
   // LDS-staged full-line stores of the 8-phase kernel run it at 157 us, the ring kernels' 256 x 256 configuration at 525 us
   if (K < 512) return epilogue == VTP_EPI_BF16 && tiles >= 1024;
   switch (epilogue) {
-    case VTP_EPI_F32:
+    case VTP_EPI_F32: return tiles >= 128;  // (96 tiles = the pixel decoder's 8192 x 768: the 128 x 64 ring tiles win by 12-18 %)
     case VTP_EPI_SWIGLU: return tiles >= 96;
     case VTP_EPI_BF16:
     case VTP_EPI_GELU: return tiles >= (K < 1024 ? 192 : 96);
