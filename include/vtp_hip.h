@@ -79,6 +79,9 @@ int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks);
  * {start, operands staged, loop done, gradients stored} written by the resident attention backward kernels (dQ kernel, then the
  * dK/dV kernel), null = off.  Process-global; not part of the reference-facing surface. */
 int vtp_attn_debug(void* timing, int lds_pad, int waves_per_wg, int stagger_ticks);  /* lds_pad: extra dynamic LDS bytes per workgroup; waves_per_wg: 0 = heuristic */
+/* host-only: the kernel configuration vtp_gemm_nt picks for a shape (8 = 256x256 8-phase, 7 = 128x64 ring tiles, other ids = ring
+ * configurations; bits 8.. = in-launch split-K slices when > 1); -1 for a bad shape.  No launch, no device needed. */
+int vtp_gemm_nt_config(int M, int N, int K, int epilogue);
 int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                 const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                 int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream);

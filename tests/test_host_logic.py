@@ -335,3 +335,26 @@ def test_bench_flop_accounting_matches_survey():
     assert abs(b.vit_fwd_gflop(1024, swiglu_hidden(1024), 24, 1025, 1024, True) - 724.91) < 0.02 * 724.91
     assert abs(3 * (46.42 + 46.23) - 277.9) < 0.1  # the rec-only train-step figure the bench's step_frac is built on
     assert set(b.WORKLOADS) >= {"vtp_base_full", "vtp_small_rec", "vtp_large_full_512"} and "vtp_large_fp8_fwd" in b.FORWARD_WORKLOADS
+
+
+def test_gemm_dispatch_table_of_the_step():
+    """vtp_gemm_nt_config (host-only): the measured kernel choice for the GEMM shapes of the VTP-B step -- 8 = 256x256 8-phase
+    kernel, 7 = 128x64 ring tiles, 5 / 0 = 128x128 ring; slices = in-launch split-K.  Pinned because every row is a measurement
+    (profiles/r03_gemm8p_bench.log, tools/text_gemm_ab.py, tools/proto_gemm_ab.py) that an edit of the heuristics can silently undo."""
+    from vtp_amd import _lib, ops
+    lib = _lib.load()
+    BF, F32, SW, GELU = ops.EPI_BF16, ops.EPI_F32, ops.EPI_SWIGLU, ops.EPI_GELU
+    want = {
+        # list forward / backward of the trunk (34144 rows), teacher (16448), pixel decoder (8192)
+        (34144, 2304, 768, BF): (8, 0), (34144, 768, 768, F32): (8, 0), (34144, 4096, 768, SW): (8, 0), (34144, 768, 2048, F32): (8, 0),
+        (34144, 768, 4096, BF): (8, 0), (34144, 2048, 768, BF): (8, 0), (16448, 768, 768, F32): (8, 0), (16448, 4096, 768, SW): (8, 0),
+        (8192, 2304, 768, BF): (8, 0), (8192, 4096, 768, SW): (8, 0), (8192, 768, 4096, BF): (8, 2),
+        (8192, 768, 2048, F32): (7, 0), (8192, 768, 768, F32): (7, 0),
+        # text tower (32 x 77 rows) and DINO head
+        (2464, 768, 3072, F32): (7, 0), (2464, 768, 3072, BF): (7, 0), (2464, 2304, 768, BF): (7, 0), (2464, 3072, 768, GELU): (5, 0),
+        (2816, 65536, 256, BF): (8, 0), (2816, 2048, 2048, GELU): (5, 0), (2816, 256, 2048, F32): (7, 0),
+    }
+    for shape, (cfg, slices) in want.items():
+        got = lib.vtp_gemm_nt_config(*shape)
+        assert (got & 255, got >> 8) == (cfg, slices), (shape, got & 255, got >> 8)
+    assert lib.vtp_gemm_nt_config(0, 768, 768, BF) == -1

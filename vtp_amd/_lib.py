@@ -49,6 +49,7 @@ SIGNATURES = {
     "vtp_qk_norm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "vtp_qk_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "vtp_set_gemm_tuning": [_I, _I],
+    "vtp_gemm_nt_config": [_I, _I, _I, _I],
     "vtp_gemm_debug": [_P, _I, _I],
     "vtp_attn_debug": [_P, _I, _I, _I],
     "vtp_norm_fwd_e4m3": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

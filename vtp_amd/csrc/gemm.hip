@@ -514,6 +514,18 @@ extern "C" int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle) {
   return VTP_OK;
 }
 
+// host-only: which kernel configuration vtp_gemm_nt picks for a shape (no launch): 8 = 256x256 8-phase kernel, 7 = 128x64 ring
+// tiles, 5 / 0 / 21 / 4 / ... = the other ring configurations; bits 8.. = in-launch split-K slices when > 1.  Lets the dispatch
+// table be pinned by a CPU test (tests/test_host_logic.py) -- the policy is measured per shape and easy to break by an edit.
+extern "C" int vtp_gemm_nt_config(int M, int N, int K, int epilogue) {
+  if (M <= 0 || N <= 0 || K <= 0) return -1;
+  int cfg = pick_cfg(M, N, K, epilogue, 1);
+  int cs = 1;
+  if (g_force_cfg < 0 && epilogue <= VTP_EPI_GELU) cs = combine_splits(M, N, K);
+  if (cs > 1) cfg = 8;
+  return cfg | (cs > 1 ? cs << 8 : 0);
+}
+
 extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* C2, int ldc2,
                            const float* bias, const float* gamma, const float* resid, int M, int N, int K, int epilogue,
                            int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream) {
