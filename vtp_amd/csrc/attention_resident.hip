@@ -1224,7 +1224,9 @@ int attn_resident_bwd(const void* q, const void* k, const void* v, const void* o
   }
   const int nw = a.npad / 32;
   auto fits = [&](int W) { return nw == W || (nw == W + 1 && N - 32 * W <= PB_XROWS); };
-  if (g_attn_wpb == 0 && (fits(PB_WAVES) || fits(2))) {
+  // (the LDS-DMA of the fused kernel addresses a head's rows with 32-bit byte offsets from a 64-bit base)
+  const bool off32 = (long)N * sn * 2 < (1L << 31) && (long)N * sno * 2 < (1L << 31);
+  if (g_attn_wpb == 0 && off32 && (fits(PB_WAVES) || fits(2))) {
     // fused kernel: one workgroup of W waves per head, the four operand images in LDS
     auto lds_of = [](int npad, int W) { return 4 * npad * 128 + 8 * npad + 3 * (W + 1) * PB_XROWS * 256; };
     static bool attr_p = false;
