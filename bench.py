@@ -2,6 +2,7 @@
 """bench.py -- VTP training-step throughput on MI355X (the BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (no launcher in the environment: re-runs itself under the next form)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -44,6 +45,7 @@ _SMALL = dict(vision_embed_dim=384, vision_depth=12, vision_num_heads=6, text_em
 _LARGE = dict(vision_embed_dim=1024, vision_depth=24, vision_num_heads=16, text_embed_dim=1024, text_depth=24,
               text_num_heads=16, decoder_embed_dim=1024, decoder_depth=24, decoder_num_heads=16)
 PEAK_FP8_TFLOPS = 5000.0
+ROLL = {}   # N > 1: result of the rank roll-call all-reduce (ranks seen, backend, RCCL version) -> `comm` of the JSON line
 # forward-only workloads (no optimizer step): BASELINE config 5
 FORWARD_WORKLOADS = {
     "vtp_large_fp8_fwd": (_LARGE, 64, 256),   # VTP-L encode -> decode, fp8 (e4m3) MFMA GEMMs, 64 img/GPU
@@ -270,6 +272,27 @@ def bench_forward(args, world, rank, dev):
         torch.distributed.destroy_process_group()
 
 
+def self_launch(n: int):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): re-run the same command line
+    under `python -m torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1 and a free port; rank 0's JSON line goes
+    to this process's stdout unchanged and the launcher's exit code is ours.  The torchrun form of the docstring keeps working
+    (it sets WORLD_SIZE, so this function is never reached)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    # host side of a rank = mask collate + launch enqueue: N ranks must not each spin up one OpenMP thread per host core
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] no launcher in the environment: re-running under torch.distributed.run with {n} ranks (port {port}, "
+          f"OMP_NUM_THREADS={env['OMP_NUM_THREADS']})", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,8 +320,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     # VTP_BENCH_BACKEND=gloo + VTP_BENCH_SHARE_GPU=1: control-flow rehearsal of the N > 1 path on a one-GPU box (all ranks on
     # device 0, gloo collectives); never used for reported numbers -- config.parallelism records it
     backend = os.environ.get("VTP_BENCH_BACKEND", "nccl")
@@ -321,8 +344,11 @@ def main():
         seen = torch.zeros(world, dtype=torch.int32, device=dev)
         seen[rank] = 1 + local
         dist.all_reduce(seen)
+        ROLL["ranks_seen"] = int((seen > 0).sum())
+        ROLL["backend"] = backend
         if rank == 0:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "-"
+            ROLL["rccl_version"] = ver
             print(f"[bench] {world} ranks up (backend {backend}, RCCL {ver}); local devices {[int(v) - 1 for v in seen.tolist()]}",
                   file=sys.stderr, flush=True)
 
@@ -408,7 +434,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            state["comm"] = {"exposed_ms_per_step": round(trainer.comm_exposed_ms() / steps, 3),
+            state["comm"] = {**ROLL, "exposed_ms_per_step": round(trainer.comm_exposed_ms() / steps, 3),
                              "payload_mb_per_step": round(trainer.bucketer.comm_bytes / steps / 1e6, 1),
                              "gradient_exchange": ("reduce-scatter (" + args.grad_dtype + ") + rank-sharded AdamW + fp32 parameter all-gather")
                              if trainer.shard_optimizer else "bucketed fp32 all-reduce + replicated AdamW"}

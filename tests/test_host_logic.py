@@ -358,3 +358,32 @@ def test_gemm_dispatch_table_of_the_step():
         got = lib.vtp_gemm_nt_config(*shape)
         assert (got & 255, got >> 8) == (cfg, slices), (shape, got & 255, got >> 8)
     assert lib.vtp_gemm_nt_config(0, 768, 768, BF) == -1
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` with no launcher in the environment must re-run itself under torch.distributed.run with N ranks
+    on 127.0.0.1 (the driver's 8-GPU command is the plain one); with WORLD_SIZE set it must not."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("_bench_sl", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ei:
+        b.main()
+    assert ei.value.code == 7  # the launcher's exit code is passed through
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["OMP_NUM_THREADS"] == str(max(1, (os.cpu_count() or 8) // 8))
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
