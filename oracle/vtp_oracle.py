@@ -96,11 +96,16 @@ def layernorm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # blocks
 # --------------------------------------------------------------------------------------------
+def _plain_linear(x: Tensor, w: Tensor, b: Optional[Tensor], site: str) -> Tensor:
+    return F.linear(x, w, b)
+
+
 def self_attention(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int,
-                   rope: Optional[Tuple[Tensor, Tensor]]) -> Tensor:
-    """SelfAttention.forward / compute_attention -- attention.py:91-96,110-126."""
+                   rope: Optional[Tuple[Tensor, Tensor]], lin=_plain_linear) -> Tensor:
+    """SelfAttention.forward / compute_attention -- attention.py:91-96,110-126.
+    lin(x, w, b, site): the linear map; F.linear unless a test substitutes a simulated low-precision GEMM (oracle/fp8_oracle.py)."""
     B, N, C = x.shape
-    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = lin(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"], pre + "qkv")
     qkv = qkv.reshape(B, N, 3, num_heads, C // num_heads)
     q, k, v = torch.unbind(qkv, 2)
     q, k, v = [t.transpose(1, 2) for t in (q, k, v)]
@@ -113,17 +118,17 @@ def self_attention(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int,
         q, k = q.to(v.dtype), k.to(v.dtype)
     o = F.scaled_dot_product_attention(q, k, v)  # scale 1/sqrt(d), no mask  (attention.py:124)
     o = o.transpose(1, 2).reshape(B, N, C)
-    return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return lin(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"], pre + "proj")
 
 
-def swiglu_ffn(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
+def swiglu_ffn(x: Tensor, sd: Dict[str, Tensor], pre: str, lin=_plain_linear) -> Tensor:
     """SwiGLUFFN.forward -- ffn.py:77-81."""
-    x1 = F.linear(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"])
-    x2 = F.linear(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"])
-    return F.linear(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
+    x1 = lin(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"], pre + "w1")
+    x2 = lin(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"], pre + "w2")
+    return lin(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"], pre + "w3")
 
 
-def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, norm: str, drop=None) -> Tensor:
+def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, norm: str, drop=None, lin=_plain_linear) -> Tensor:
     """SelfAttentionBlock._forward -- block.py:207-233.  Default: the eval / drop_ratio == 0 branch (:290-296); LayerScale
     (misc.py:24-25) is applied when the checkpoint has `ls1.gamma` / `ls2.gamma` (Identity otherwise, block.py:173,185).
     drop = (idx1, alpha1, idx2, alpha2): the training branch with stochastic depth for GIVEN image subsets (the reference
@@ -139,8 +144,8 @@ def vit_block(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int, rope, 
     f1 = (lambda t: t * ls1) if ls1 is not None else (lambda t: t)
     f2 = (lambda t: t * ls2) if ls2 is not None else (lambda t: t)
     if drop is None:
-        x = x + f1(self_attention(nrm(x, "norm1"), sd, pre + "attn.", num_heads, rope))
-        x = x + f2(swiglu_ffn(nrm(x, "norm2"), sd, pre + "mlp."))
+        x = x + f1(self_attention(nrm(x, "norm1"), sd, pre + "attn.", num_heads, rope, lin))
+        x = x + f2(swiglu_ffn(nrm(x, "norm2"), sd, pre + "mlp.", lin))
         return x
     idx1, a1, idx2, a2 = drop
     r1 = self_attention(nrm(x[idx1], "norm1"), sd, pre + "attn.", num_heads, rope)
@@ -168,7 +173,7 @@ def patch_embed(img: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottleneck: bool = True,
-                  masks: Optional[Tensor] = None, pre: str = "trunk.", drop=None) -> Dict[str, Tensor]:
+                  masks: Optional[Tensor] = None, pre: str = "trunk.", drop=None, lin=_plain_linear) -> Dict[str, Tensor]:
     """DinoVisionTransformerWithBottleneck.forward(is_training=True) for ONE resolution --
     vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79."""
     x = patch_embed(img, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
@@ -182,7 +187,7 @@ def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottle
     x = torch.cat([cls.expand(B, -1, -1), x], dim=1)  # :210-217 (no storage tokens)
     rope = rope_table(H, W, sd[pre + "rope_embed.periods"])
     for i in range(_depth(sd, pre + "blocks.")):
-        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm", drop=None if drop is None else drop[i])
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm", drop=None if drop is None else drop[i], lin=lin)
     xn = rmsnorm(x, sd[pre + "norm.weight"], 1e-5)  # :246
     cls_t, patch_t = xn[:, 0], xn[:, 1:]
     if use_bottleneck and (pre + "feature_bottleneck.weight") in sd:  # bottleneck.py:66-79
@@ -217,9 +222,9 @@ def intermediate_layers(sd, img, num_heads, n=1, reshape=False, return_class_tok
     return tuple(zip(outs, cls_t)) if return_class_token else tuple(outs)
 
 
-def reconstruction_latents(sd, img, num_heads) -> Tensor:
+def reconstruction_latents(sd, img, num_heads, lin=_plain_linear) -> Tensor:
     """VTPModel.get_reconstruction_latents -- modeling_vtp.py:337-360,379-395."""
-    out = trunk_forward(sd, img, num_heads, use_bottleneck=True)
+    out = trunk_forward(sd, img, num_heads, use_bottleneck=True, lin=lin)
     pt = out["x_norm_patchtokens"]
     B, N, C = pt.shape
     return pt.transpose(1, 2).reshape(B, C, img.shape[-2] // 16, img.shape[-1] // 16)
@@ -228,14 +233,15 @@ def reconstruction_latents(sd, img, num_heads) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # pixel decoder -- vtp/models/decoders/pixel_decoder.py:134-162
 # --------------------------------------------------------------------------------------------
-def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.", drop=None) -> Tensor:
+def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.", drop=None,
+                    lin=_plain_linear) -> Tensor:
     B, _, H, W = latents.shape
     x = F.conv2d(latents, sd[pre + "proj_in.weight"], sd[pre + "proj_in.bias"])  # :138
     D = x.shape[1]
     x = x.flatten(2).transpose(1, 2)  # :141
     rope = rope_table(H, W, sd[pre + "rope_embed.periods"])  # :144
     for i in range(_depth(sd, pre + "blocks.")):
-        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm", drop=None if drop is None else drop[i])
+        x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm", drop=None if drop is None else drop[i], lin=lin)
     x = layernorm(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-6)  # :151
     x = x.transpose(1, 2).reshape(B, D, H, W)  # :154
     x = F.conv2d(x, sd[pre + "proj_out.weight"], sd[pre + "proj_out.bias"])  # :157

@@ -1,6 +1,8 @@
 """fp8 (e4m3) forward path of BASELINE config 5: quantisation kernels bit-exact against torch's float8_e4m3fn cast, the fp8 MFMA GEMM
-against an fp32 matmul of the SAME quantised operands (so only accumulation order differs), and the end-to-end encode -> decode
-error against the bf16 path."""
+against an fp32 matmul of the SAME quantised operands (so only accumulation order differs), the end-to-end encode -> decode
+error against the bf16 path, and -- the parity statement of the configuration -- encode / decode outputs
+against the ORACLE in fp32 with E_ref taken from the oracle's e4m3-simulated forward (oracle/fp8_oracle.py: the reference
+algorithm with the same four GEMM operand pairs per block round-tripped through torch.float8_e4m3fn at per-tensor scales)."""
 import pytest
 import torch
 
@@ -95,3 +97,55 @@ def test_fp8_encode_decode_vs_bf16_path():
                                  text_depth=1, text_num_heads=2, text_vocab_size=64, text_context_length=8, decoder_embed_dim=128,
                                  decoder_depth=1, decoder_num_heads=2)).to(DEV).eval()
         bad.enable_fp8_forward(img[:2])
+
+
+_TINY4 = dict(image_size=64, vision_embed_dim=192, vision_depth=4, vision_num_heads=3, text_embed_dim=128, text_depth=1,
+              text_num_heads=2, text_vocab_size=64, text_context_length=8, decoder_embed_dim=192, decoder_depth=4,
+              decoder_num_heads=3)
+_LARGE24 = dict(vision_embed_dim=1024, vision_depth=24, vision_num_heads=16, decoder_embed_dim=1024, decoder_depth=24,
+                decoder_num_heads=16, text_embed_dim=128, text_depth=1, text_num_heads=2, text_vocab_size=64, text_context_length=8)
+
+
+@pytest.mark.parametrize("name,cfg_kw,heads,B,res", [("4-block D=192", _TINY4, 3, 8, 64), ("VTP-L 24-block (config 5)", _LARGE24, 16, 2, 256)])
+def test_fp8_encode_decode_vs_e4m3_simulated_oracle(name, cfg_kw, heads, B, res):
+    """|ours_fp8 - oracle_fp32| <= 1.25 x |oracle_fp8sim - oracle_fp32| on the latents, on the decoder output for the SAME
+    (reference) latents and end to end; E_ref = the larger of the simulated forward under CPU and CUDA bf16 autocast (the
+    like-for-like precision of everything outside the GEMM operands).  The fp32-everything-else simulation is printed too."""
+    from oracle import fp8_oracle as F8
+    from vtp_amd import VTPConfig, VTPModel
+    torch.manual_seed(3)
+    m = VTPModel(VTPConfig(**cfg_kw))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim <= 1 and n != "logit_scale":
+                p.add_(0.02 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    img = torch.randn(B, 3, res, res, generator=torch.Generator().manual_seed(5))
+    calib = img[: max(2, B // 2)]
+    with torch.no_grad():
+        lat_ref, rec_ref = F8.encode_decode(sd, img, heads, heads)               # fp32 reference algorithm
+        sim = F8.calibrate(sd, calib, heads, heads)
+        sims = {"fp32": (F8.encode_decode(sd, img, heads, heads, lin=sim), F8.O.decoder_forward(sd, lat_ref, heads, lin=sim))}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            sims["cpu16"] = (F8.encode_decode(sd, img, heads, heads, lin=sim), F8.O.decoder_forward(sd, lat_ref, heads, lin=sim))
+        sd_g = {k: v.to(DEV) for k, v in sd.items()}
+        sim_g = F8.Fp8Sim(sd_g)
+        sim_g.amax, sim_g.mode = dict(sim.amax), "apply"
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            sims["gpu16"] = (F8.encode_decode(sd_g, img.to(DEV), heads, heads, lin=sim_g),
+                             F8.O.decoder_forward(sd_g, lat_ref.to(DEV), heads, lin=sim_g))
+        m.enable_fp8_forward(calib.to(DEV))
+        lat = m.get_reconstruction_latents(img.to(DEV))
+        rec_e2e = m.get_latents_decoded_images(lat)
+        rec_same = m.get_latents_decoded_images(lat_ref.to(DEV))
+    ours = {"latents": (lat, lat_ref), "decoder(same latents)": (rec_same, rec_ref), "end-to-end": (rec_e2e, rec_ref)}
+    pick = {"latents": lambda t: t[0][0], "decoder(same latents)": lambda t: t[1], "end-to-end": lambda t: t[0][1]}
+    for what, (o, ref) in ours.items():
+        e = relF(o, ref)
+        er = {tag: relF(pick[what](sims[tag]), ref) for tag in sims}
+        e_ref = max(er["cpu16"], er["gpu16"])
+        print(f"PARITY fp8 [{name}] {what}: E_ours={e:.3e} E_ref(fp8-sim: fp32 rest)={er['fp32']:.3e} (cpu autocast)={er['cpu16']:.3e} "
+              f"(cuda autocast)={er['gpu16']:.3e} E_ours/E_ref={e / e_ref:.2f}")
+        assert e <= 1.25 * e_ref, (name, what, e, e_ref)
+        assert e > 0.2 * er["fp32"], "suspiciously exact: did the fp8 path run?"

@@ -213,6 +213,30 @@ def _attn_ref(q, k, v, causal):
     return F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2)
 
 
+def _sdpa_bf16_errors(q, k, v, d_o, causal, ref_grads):
+    """(relF, max|err|) of the bf16 execution of the reference op (F.scaled_dot_product_attention + autograd, attention.py:124)
+    against the fp32 gradients, per SDPA backend; returns the largest per tensor.  Test infrastructure only."""
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    worst = {}
+    ran = []
+    for be in (SDPBackend.FLASH_ATTENTION, SDPBackend.EFFICIENT_ATTENTION, SDPBackend.MATH):
+        try:
+            qb, kb, vb = (t.detach().clone().transpose(1, 2).requires_grad_(True) for t in (q, k, v))  # [B,h,N,64] bf16
+            with sdpa_kernel([be]):
+                ob = F.scaled_dot_product_attention(qb, kb, vb, is_causal=causal)
+            ob.backward(d_o.transpose(1, 2).to(ob.dtype))
+        except RuntimeError:
+            continue
+        ran.append(be.name)
+        for nm, gb, r in zip(("dq", "dk", "dv"), (qb.grad, kb.grad, vb.grad), ref_grads):
+            gb = gb.transpose(1, 2).float()
+            e = (float((gb - r).norm() / r.norm()), float((gb - r).abs().max()))
+            w = worst.get(nm, (0.0, 0.0))
+            worst[nm] = (max(w[0], e[0]), max(w[1], e[1]))
+    assert ran, "no SDPA backend ran under bf16"
+    return worst
+
+
 @pytest.mark.parametrize("B,N,heads,causal", [(2, 257, 3, False), (1, 256, 2, False), (3, 17, 2, False), (2, 77, 2, True),
                                               (1, 1025, 2, False), (2, 130, 1, True), (1, 64, 1, False),
                                               # the launches of the benchmarked list forward (VTP-B, 12 heads): local 96^2 crops
@@ -250,14 +274,22 @@ def test_attention_fwd_bwd(B, N, heads, causal):
     o.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], out, d_o, lse, delta, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], B, N, heads,
                N * 3 * D, 3 * D, N * D, D, scale, causal)
     dq, dk, dv = dqkv.view(B, N, 3, heads, 64).unbind(2)
-    # dS = P*(dP - delta) is rounded to bf16 before the dQ/dK MFMAs and delta is formed from the bf16 O: on the
-    # spiked (near one-hot) row this cancellation leaves a few outliers -> looser max bound, tight Frobenius bound
-    check(dv, vr.grad, "attn_bwd dv", scale=1e-2)
-    check(dq, qr.grad, "attn_bwd dq", scale=3e-2)
-    check(dk, kr.grad, "attn_bwd dk", scale=3e-2)
+    # Bar: E_ours <= slack x E_ref, where E_ref is the error of the SAME op under bf16 -- stock PyTorch-ROCm
+    # F.scaled_dot_product_attention forward + autograd backward on the identical bf16 q, k, v, dO, every SDPA backend that
+    # accepts the shape (flash / mem-efficient / math), the largest of them -- against the fp32 reference.  dS = P (dP - delta)
+    # is rounded to bf16 before the dQ / dK MFMAs and delta is formed from the bf16 O: on the spiked (near one-hot) row this
+    # cancellation leaves outliers in ANY bf16 execution, which is what E_ref measures.  Frobenius: slack 1.25; max|err| is an
+    # extreme-value statistic of one run, slack 2.  No absolute bounds.
+    e_ref = _sdpa_bf16_errors(q, k, v, d_o.view(B, N, heads, 64), causal, (qr.grad, kr.grad, vr.grad))
     for nm, a, r in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
-        e = float((a.float() - r).norm() / r.norm())
-        assert e < 1.5e-2, f"attn_bwd {nm}: relF {e:.3e}"
+        assert not torch.isnan(a.float()).any(), f"attn_bwd {nm}: NaN"
+        eF = float((a.float() - r).norm() / r.norm())
+        eM = float((a.float() - r).abs().max())
+        rF, rM = e_ref[nm]
+        print(f"[attn_bwd {nm} N={N} B={B} h={heads} causal={causal}] relF ours={eF:.3e} ref(bf16 SDPA)={rF:.3e} ratio={eF / rF:.2f} | "
+              f"max|err| ours={eM:.3e} ref={rM:.3e} ratio={eM / rM:.2f}")
+        assert eF <= 1.25 * rF, f"attn_bwd {nm}: relF {eF:.3e} > 1.25 x E_ref {rF:.3e}"
+        assert eM <= 2.0 * rM, f"attn_bwd {nm}: max|err| {eM:.3e} > 2 x E_ref {rM:.3e}"
     if not causal:
         # inverse RoPE fused into the backward (short sequences: in the kernels' stores; long: appended pass) is bit-identical
         # to running vtp_rope_qk(inverse) on the plain result; the cls row (prefix 1) stays un-rotated

@@ -59,13 +59,14 @@ class Case:
     """Seeded VTP-B + DINO head (K = 65536) + EMA teacher, one SSL batch, and the oracle's results in fp32 / CPU autocast /
     CUDA autocast: head outputs, the SSL loss with its gradients, and the full step's loss with its gradients."""
 
-    def __init__(self):
+    def __init__(self, cfg_kw=None, heads=(HV, HD, HT), K=65536, res=256, seed=31):
         from oracle import vtp_oracle as O
         from vtp_amd import VTP, VTPConfig
         from vtp_amd.data import collate_ssl_masks
         self.O = O
-        torch.manual_seed(31)
-        m = VTP(VTPConfig(), dino_out_dim=65536)
+        HV, HD, HT = self.heads = heads
+        torch.manual_seed(seed)
+        m = VTP(VTPConfig(**(cfg_kw or {})), dino_out_dim=K)
         with torch.no_grad():
             for n, p in m.named_parameters():
                 if p.ndim <= 1 and n != "logit_scale" and not n.startswith("teacher_"):
@@ -80,13 +81,12 @@ class Case:
         self.model = m.to(DEV)
         B = 2
         g = torch.Generator().manual_seed(7)
-        self.img = torch.randn(B, 3, 256, 256, generator=g)
-        self.txt = _captions(B, 77, 49408, 8)
-        self.gc = torch.randn(2 * B, 3, 256, 256, generator=g)
+        self.img = torch.randn(B, 3, res, res, generator=g)
+        self.txt = _captions(B, m.config.text_context_length, m.config.text_vocab_size, 8)
+        self.gc = torch.randn(2 * B, 3, res, res, generator=g)
         self.lc = torch.randn(N_LOCAL * B, 3, 96, 96, generator=g)
-        col = collate_ssl_masks(2 * B, (16, 16), 0.5, (0.1, 0.5), np.random.default_rng(11))
+        col = collate_ssl_masks(2 * B, (res // 16, res // 16), 0.5, (0.1, 0.5), np.random.default_rng(11))
         self.col, self.masks = col, col["masks"]
-        K = 65536
         self.c_d = 0.3 * torch.randn(K, generator=g)
         self.c_i = 0.3 * torch.randn(K, generator=g)
         self.out, self.grads_ssl, self.grads_full, self.loss = {}, {}, {}, {}

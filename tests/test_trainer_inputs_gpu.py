@@ -90,3 +90,22 @@ def test_per_objective_drop_rates(golden_sd):
     tr2 = VTPTrainer(_model(golden_sd), lr=1e-3, weight_decay=0.0, drop_rate=0.5, drop_seed=1)
     tr2.step(a, txt)
     assert tr2.trunk.stack.last_drop_plan["batches"] == [4]
+
+
+def test_prepare_ssl_batches_keep_their_index_tensors():
+    """a loader that prepares many batches ahead (more than the staging ring has pinned slots) must find every
+    batch's device index / mask tensors intact -- they are owned allocations, not views of a recycled ring slot."""
+    import numpy as np
+    from vtp_amd.train import HostStager
+    st = HostStager(torch.device(DEV), slots=4)
+    rng = np.random.default_rng(0)
+    sent, got = [], []
+    for i in range(9):
+        arrays = {"idx": rng.integers(0, 1000, size=257 + i).astype(np.int32), "w": rng.random(33).astype(np.float32),
+                  "masks": (rng.random((4, 16)) < 0.3).astype(np.uint8)}
+        sent.append(arrays)
+        got.append(st.upload(arrays))
+    torch.cuda.synchronize()
+    for arrays, up in zip(sent, got):
+        for k, a in arrays.items():
+            assert up[k].shape == a.shape and np.array_equal(up[k].cpu().numpy(), a), k

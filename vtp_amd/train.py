@@ -140,16 +140,18 @@ class GradBucketer:
 
 class HostStager:
     """Per-step host -> device upload of small index / mask arrays WITHOUT stalling the host: the arrays of one batch are packed
-    into a slot of a pinned ring and sent with ONE non-blocking copy; the device tensors handed out are views of the slot's
-    device buffer.  (A plain `torch.as_tensor(numpy_array, device=...)` copies from pageable memory, and PyTorch synchronises the
-    stream for that: the host would wait for the whole previous step before it can prepare the next one -- measured 45 ms of a
-    54 ms step spent inside prepare_ssl.)  A slot is reused only after the copy that read it has executed (its event), and every
-    later use of its device buffer is ordered behind the consumers on the same stream."""
+    into a slot of a PINNED host ring and sent with ONE non-blocking copy.  (A plain `torch.as_tensor(numpy_array, device=...)`
+    copies from pageable memory, and PyTorch synchronises the stream for that: the host would wait for the whole previous step
+    before it can prepare the next one -- measured 45 ms of a 54 ms step spent inside prepare_ssl.)
+
+    Lifetimes: only the pinned HOST slots are recycled (a slot is rewritten after the copy that read it has executed: its
+    event).  The DEVICE side of every upload is a fresh allocation from torch's caching allocator that the returned tensors own
+    -- a loader may prepare any number of batches ahead and a caller may keep an `ssl` dict across later prepare_ssl calls
+    (the earlier version handed out views of a 4-slot device ring, which the 5th upload overwrote in place)."""
 
     def __init__(self, device, slots: int = 4):
         self.device, self.n, self.i = device, slots, 0
         self.host = [None] * slots
-        self.dev = [None] * slots
         self.events = [None] * slots
 
     def upload(self, arrays: dict) -> dict:
@@ -165,14 +167,13 @@ class HostStager:
         if self.events[slot] is not None:
             self.events[slot].synchronize()
         if self.host[slot] is None or self.host[slot].numel() < total:
-            cap = max(total * 2, 1 << 16)
-            self.host[slot] = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self.dev[slot] = torch.empty(cap, dtype=torch.uint8, device=self.device)
-        h, d = self.host[slot], self.dev[slot]
+            self.host[slot] = torch.empty(max(total * 2, 1 << 16), dtype=torch.uint8).pin_memory()
+        h = self.host[slot]
         hn = h.numpy()
         for k, a, o in plan:
             hn[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
-        d[:total].copy_(h[:total], non_blocking=True)
+        d = torch.empty(total, dtype=torch.uint8, device=self.device)  # owned by the tensors returned below
+        d.copy_(h[:total], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.events[slot] = ev
