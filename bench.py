@@ -110,11 +110,10 @@ def vit_fwd_gflop(D, H, L, N, hw, enc: bool):
     return f / 1e9
 
 
-def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=100.0):
+def cpu_baseline(model, B_cpu, res, clip, do_ssl):
     """The CPU oracle (kind "port": oracle/vtp_oracle.py is a PyTorch restatement of the reference, itself PyTorch) timed on
     the host cores on a bounded sample of the SAME workload: one full train step (fwd + every loss that ran on the GPU + autograd
-    bwd + AdamW) at a scaled-down batch in fp32 (and, if the host-time budget allows, under torch.autocast("cpu", bf16); SURVEY.md
-    §8d): 2 warm-up + 5 timed steps, median step time."""
+    bwd + AdamW) at a scaled-down batch in fp32 and under torch.autocast("cpu", bf16) (bounded: see below)."""
     from oracle import vtp_oracle as O
     import numpy as np
     from vtp_amd.data import collate_ssl_masks
@@ -166,19 +165,18 @@ def cpu_baseline(model, B_cpu, res, clip, do_ssl, budget_s=100.0):
         ts.sort()
         return ts[len(ts) // 2], len(ts)
 
-    # SURVEY.md §8d / VERDICT r2: 2 warm-up + 5 timed fp32 steps, median.  The bf16-autocast leg (the like-for-like precision) is
-    # timed only while the whole baseline stays inside `budget_s` seconds of host time: the fp32 figure is the reported `value`.
-    t_all = time.perf_counter()
-    t32, n32 = timed(False, 2, 5)
-    auto = None
-    if time.perf_counter() - t_all + 4 * t32 < budget_s:
-        t16, n16 = timed(True, 1, 3)
-        auto = {"value": round(B_cpu / t16, 3), "unit": "images/sec", "steps": n16,
-                "note": 'same step under torch.autocast("cpu", dtype=torch.bfloat16), 1 warm-up'}
+    # SURVEY.md §8d asks for bs 8, 2 warm-up + 10 timed steps in fp32 AND under bf16 autocast; the full step (K = 65536 prototypes, 10
+    # crops per image) costs ~8 s per image on a 128-thread host, so that protocol would be ~25 minutes.  Bounded sample (task
+    # contract: tens of seconds of CPU work): batch 2, fp32 1 warm-up + 2 timed steps, bf16 autocast 1 warm-up + 1 timed step -- both
+    # legs always run; the fp32 figure is the reported `value`.
+    t32, n32 = timed(False, 1, 2)
+    t16, n16 = timed(True, 1, 1)
+    auto = {"value": round(B_cpu / t16, 3), "unit": "images/sec", "steps": n16, "ms_per_step": round(t16 * 1e3, 1),
+            "note": 'same step under torch.autocast("cpu", dtype=torch.bfloat16), 1 warm-up'}
     objs = "L1" + ("+CLIP" if clip else "") + ("+DINO/iBOT (K=%d prototypes, 2 global + 8 local crops/img, EMA-teacher fwd)" % K if do_ssl else "")
     return {"value": round(B_cpu / t32, 3), "unit": "images/sec", "cores": n_thr, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"median of {n32} fp32 train steps (fwd + {objs} loss + bwd + AdamW) of the same model at batch {B_cpu} "
-                      f"after 2 warm-up steps",
+                      f"after 1 warm-up step; SURVEY §8d's bs-8 / 10-step protocol is ~25 min of host time and is not run",
             "bf16_autocast": auto, "ms_per_step_fp32": round(t32 * 1e3, 1), "threads": n_thr}
 
 
@@ -301,7 +299,7 @@ def main():
     ap.add_argument("--workload", default="vtp_base_full", choices=sorted(WORKLOADS) + sorted(FORWARD_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1, help="images per CPU-oracle step (the full step costs ~9 s per image on a 128-thread host)")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="images per CPU-oracle step (the full step costs ~8 s per image on a 128-thread host)")
     ap.add_argument("--no-lpips-run", action="store_true", help="skip the second measurement with the perceptual term on")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
     ap.add_argument("--no-separate-run", action="store_true",
@@ -471,7 +469,11 @@ def main():
             M = kw["M"] if kw.get("M") is not None else a.shape[0]
             K = kw["K"] if kw.get("K") is not None else a.shape[1]
             N = kw["N"] if kw.get("N") is not None else b.shape[0]
-            recs.append((2.0 * M * N * K, e0, e1, (fn.__name__, M, N, K, kw.get("epi", 0), kw.get("splits", 1))))
+            epi, sp = kw.get("epi", 0), kw.get("splits", 1)
+            # algorithmic HBM bytes: operands once + result once (+ residual read; SwiGLU: x12 and hidden; GELU: pre-activation and output)
+            out_b = {ops.EPI_BF16: 2.0, ops.EPI_F32: 4.0 + (4.0 if kw.get("resid") is not None else 0.0), ops.EPI_SWIGLU: 3.0,
+                     ops.EPI_GELU: 4.0 if kw.get("c2") is not None else 2.0, ops.EPI_F32_ATOMIC: 8.0, ops.EPI_F32_SLAB: 4.0 * sp}.get(epi, 4.0)
+            recs.append((2.0 * M * N * K, e0, e1, (fn.__name__, M, N, K, epi, sp), 2.0 * K * (M + N) + out_b * M * N))
         return run
 
     def timed_qkv(a, w, bias, c, M, N, K, *rest):
@@ -479,14 +481,14 @@ def main():
         e0.record()
         orig_qkv(a, w, bias, c, M, N, K, *rest)
         e1.record()
-        recs.append((2.0 * M * N * K, e0, e1, ("gemm_qkv_rope", M, N, K, 0, 1)))
+        recs.append((2.0 * M * N * K, e0, e1, ("gemm_qkv_rope", M, N, K, 0, 1), 2.0 * K * (M + N) + 2.0 * M * N))
 
     def timed_dsw(dy, wT, x12, dx12, M, H, K):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig_dsw(dy, wT, x12, dx12, M, H, K)
         e1.record()
-        recs.append((2.0 * M * H * K, e0, e1, ("gemm_dgrad_swiglu", M, H, K, 0, 1)))
+        recs.append((2.0 * M * H * K, e0, e1, ("gemm_dgrad_swiglu", M, H, K, 0, 1), 2.0 * K * (M + H) + 8.0 * M * H))  # + x12 read, dx12 written
 
     orig_grp = ops.WgradGroup.launch
 
@@ -496,7 +498,8 @@ def main():
         orig_grp(self)
         e1.record()
         fl = sum(2.0 * r[7] * r[8] * self.Ktok for r in self.rows)
-        recs.append((fl, e0, e1, ("gemm_tn_grouped", len(self.rows), self.ntiles, self.Ktok, 1, self.splits)))
+        by = sum(2.0 * self.Ktok * (r[7] + r[8]) + 4.0 * r[7] * r[8] * (2 if r[12] else 1) for r in self.rows)  # dy + x read, dW written (+ read: C +=)
+        recs.append((fl, e0, e1, ("gemm_tn_grouped", len(self.rows), self.ntiles, self.Ktok, 1, self.splits), by))
 
     if rank == 0:
         ops.gemm_nt, ops.gemm_tn, ops.gemm_qkv_rope, ops.gemm_dgrad_swiglu = timed(orig_nt), timed(orig_tn), timed_qkv, timed_dsw
@@ -522,7 +525,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         if os.environ.get("VTP_BENCH_GEMM_TABLE"):  # per-shape in-situ table of the instrumented step (tuning aid)
             tab = {}
-            for f, a, b, key in recs:
+            for f, a, b, key, _by in recs:
                 t = tab.setdefault(key, [0, 0.0, 0.0])
                 t[0] += 1
                 t[1] += a.elapsed_time(b)
@@ -531,24 +534,41 @@ def main():
                 for key, (n, t, f) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                     fh.write(f"{key[0]:14s} M={key[1]:6d} N={key[2]:6d} K={key[3]:6d} epi={key[4]} splits={key[5]:2d}  calls={n:3d}  "
                              f"total={t:7.3f} ms  avg={t / n * 1e3:7.1f} us  {f / t / 1e9:7.1f} TF/s\n")
-        traffic, traffic_src = None, None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
+        traffic, traffic_src, mfma_util, pmc_extra = None, None, None, None
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
         if pmc and args.workload == "vtp_base_full" and not args.batch:
-            try:  # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes of this command
+            try:  # HBM bytes per launch and SQ counters of the same kernels from the committed rocprofv3 --pmc passes of this command
                 d = json.load(open(pmc))
-                by, n = 0.0, 0
-                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn"):
+                by, n, busy, gui = 0.0, 0, 0.0, 0.0
+                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn", "gemm8h_nt"):
                     if fam not in d:
                         continue
                     # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2, MI355X_MICROARCH.md HBM)
                     by += 1024.0 * (2.0 * d[fam]["FETCH_SIZE"]["sum"] + d[fam]["WRITE_SIZE"]["sum"])
                     n += d[fam]["FETCH_SIZE"]["dispatches"]
+                    if "SQ_VALU_MFMA_BUSY_CYCLES" in d[fam]:
+                        busy += d[fam]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"]
+                        gui += d[fam]["GRBM_GUI_ACTIVE"]["sum"]
                 traffic, traffic_src = round(by / n), f"profiles/{os.path.basename(pmc)} (separate --pmc passes; bytes per launch)"
-            except (KeyError, ValueError):
+                if gui > 0:
+                    # matrix-pipe busy cycles / SIMD-cycles while the kernels ran (tools/pmc_summarize.py `derived`: GRBM_GUI_ACTIVE is
+                    # summed over the 8 XCDs; 1024 SIMDs); attention alongside, from the same pass
+                    mfma_util = round(busy / (gui / 8.0 * 1024.0), 4)
+                    pmc_extra = {k: {m: d[k][m] for m in ("mfma_util", "valu_busy", "lds_bank_conflict_frac") if m in d[k]}
+                                 for k in ("gemm8p_nt", "gemm8h_nt", "gemm8p_grouped_tn", "gemm_nt", "attn_fwd", "attn_bwd_fused") if k in d}
+            except (KeyError, ValueError, ZeroDivisionError):
                 pass
+        # algorithmic HBM bytes of the same launches: every operand read once, every result written once (+ the residual / pre-
+        # activation reads of the fused epilogues) -- what `traffic` is to be compared with
+        alg = sum(r[4] for r in recs if len(r) > 4 and r[4])
         roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm8p_grouped_tn_kernel + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad, TN wgrad incl. the per-block grouped launches, 256x256 8-phase and ring tile configs, all epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch_avg": round(alg / len(recs)) if alg else None,
+                "traffic_over_algorithmic": round(traffic / (alg / len(recs)), 3) if (traffic and alg) else None,
+                "mfma_util": mfma_util, "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the GEMM family, "
+                "rocprofv3 --pmc pass of this command (profiles/); x sustained clock / 2.4 GHz = fraction of the data-sheet peak",
+                "pmc_by_kernel": pmc_extra, "launches_per_step": len(recs),
                 "avg_launch_us": round(ms * 1e3 / len(recs), 2), "gemm_ms_per_step": round(ms, 3),
                 "flop_per_launch_avg": fl / len(recs)}
     if world > 1:

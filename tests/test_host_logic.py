@@ -195,10 +195,19 @@ def test_wgrad_group_split_rule_and_overlap_lanes():
         s = lib.vtp_gemm_tn_splits(rows, cols, k)
         t256, t128 = -(-rows // 256) * -(-cols // 256), -(-rows // 128) * -(-cols // 128)
         assert s >= 1 and (s == 1 or t256 * s <= 256 or (t128 * s <= 512 and s <= 16)), (rows, cols, k, s)
+    from vtp_amd import ops
     for ktok, want in ((34144, 2), (8192, 2), (2464, 2), (514, 1), (1100, 1)):  # VTP-B block: 108 tiles of 256 x 256
-        s = max(1, min(256 // 108, ktok // 1024))
-        ks = ((ktok + s - 1) // s + 63) // 64 * 64
-        assert (ktok + ks - 1) // ks == want, (ktok, s)
+        ks, s = ops.wgrad_group_splits(108, ktok)  # the helper WgradGroup.finalize calls (test the code, not a copy of it)
+        assert s == want and ks % 64 == 0 and ks * s >= ktok, (ktok, ks, s)
+    # 32-bit staging offsets of the grouped launch: VTP-L at 512^2, 16 img/GPU (M = 16 x 1025 x ..., ld = 2H = 5472) fits; a token count
+    # x leading dimension beyond 4 GiB does not -- Stack.backward then takes the per-layer path, WgradGroup.finalize refuses
+    assert ops.wgrad_group_fits(34144, 4096) and ops.wgrad_group_fits(16 * 1025 * 3 + 128 * 37, 5472)
+    assert not ops.wgrad_group_fits(400000, 5472)
+    g = ops.WgradGroup(400000)
+    g.rows.append([0, 0, 0, 0, 5472, 1024, 1024, 5472, 1024, 0, 0, 0, 1, 0, 0, 0])
+    g.ntiles = 88
+    with pytest.raises(ValueError, match="32-bit"):
+        g.finalize("cpu")
     assert OVERLAP._lane == 0
     with OVERLAP.lane(1):
         assert OVERLAP._lane == 1
@@ -339,17 +348,19 @@ def test_bench_flop_accounting_matches_survey():
 
 def test_gemm_dispatch_table_of_the_step():
     """vtp_gemm_nt_config (host-only): the measured kernel choice for the GEMM shapes of the VTP-B step -- 8 = 256x256 8-phase
-    kernel, 7 = 128x64 ring tiles, 5 / 0 = 128x128 ring; slices = in-launch split-K.  Pinned because every row is a measurement
-    (profiles/r03_gemm8p_bench.log, tools/text_gemm_ab.py, tools/proto_gemm_ab.py) that an edit of the heuristics can silently undo."""
+    kernel, 9 = 128x256 half-size kernel with two workgroups per CU (round 4), 7 = 128x64 ring tiles, 5 / 0 = 128x128 ring; slices =
+    in-launch split-K.  Pinned because every row is a measurement (profiles/r03_gemm8p_bench.log, profiles/r04_gemm8h_bench.log,
+    tools/text_gemm_ab.py, tools/proto_gemm_ab.py) that an edit of the heuristics can silently undo."""
     from vtp_amd import _lib, ops
     lib = _lib.load()
     BF, F32, SW, GELU = ops.EPI_BF16, ops.EPI_F32, ops.EPI_SWIGLU, ops.EPI_GELU
     want = {
         # list forward / backward of the trunk (34144 rows), teacher (16448), pixel decoder (8192)
         (34144, 2304, 768, BF): (8, 0), (34144, 768, 768, F32): (8, 0), (34144, 4096, 768, SW): (8, 0), (34144, 768, 2048, F32): (8, 0),
-        (34144, 768, 4096, BF): (8, 0), (34144, 2048, 768, BF): (8, 0), (16448, 768, 768, F32): (8, 0), (16448, 4096, 768, SW): (8, 0),
+        (34144, 768, 4096, BF): (8, 0), (34144, 2048, 768, BF): (8, 0), (16448, 768, 768, F32): (8, 0), (16448, 4096, 768, SW): (9, 0),
         (8192, 2304, 768, BF): (8, 0), (8192, 4096, 768, SW): (8, 0), (8192, 768, 4096, BF): (8, 2),
-        (8192, 768, 2048, F32): (7, 0), (8192, 768, 768, F32): (7, 0),
+        (8192, 768, 2048, F32): (7, 0), (8192, 768, 768, F32): (7, 0), (8192, 768, 2304, BF): (9, 0), (8192, 768, 768, BF): (9, 0),
+        (2464, 3072, 768, BF): (9, 0),
         # text tower (32 x 77 rows) and DINO head
         (2464, 768, 3072, F32): (7, 0), (2464, 768, 3072, BF): (7, 0), (2464, 2304, 768, BF): (7, 0), (2464, 3072, 768, GELU): (5, 0),
         (2816, 65536, 256, BF): (8, 0), (2816, 2048, 2048, GELU): (5, 0), (2816, 256, 2048, F32): (7, 0),

@@ -359,9 +359,17 @@ static int swz_flags() { return g_xcd_swizzle; }
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s);
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s);
 bool gemm8p_fits(const GemmArgs& a, bool trans);
+// gemm8h.hip: 128x256 half-size variant, two workgroups per CU (cfg 9; NT, one K slice)
+int launch_gemm8h_nt(const GemmArgs& a, int epi, hipStream_t s);
 
 template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
+  if (cfg == 9) {
+    if constexpr (!TRANS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_SWIGLU || EPI == EPI_GELU)) {
+      if (splits == 1 && a.N % 256 == 0 && gemm8p_fits(a, false)) return launch_gemm8h_nt(a, EPI, s);
+    }
+    cfg = TRANS ? 5 : 8;
+  }
   if (cfg == 8) {
     if constexpr (TRANS) {
       if (a.a_grp == 0 && a.b_grp == 0 && gemm8p_fits(a, true)) return launch_gemm8p_tn(a, EPI, splits, s);
@@ -417,6 +425,27 @@ static bool use_8p_nt(int M, int N, int K, int epilogue) {
   }
 }
 
+// the 128 x 256 half-size kernel with two workgroups per CU (cfg 9, gemm8h.hip) against the dispatch above: measured per shape in
+// tools/gemm8h_bench.py (profiles/r04_gemm8h_bench.log).  Its free-running workgroup pairs use the matrix pipe ~10 % worse than the
+// 256 x 256 kernel's barrier-coupled wave groups (long-K dgrads x0.88 .. 0.92), so it is taken only where one workgroup's epilogue
+// hiding under the other's k loop, or its finer tail, outweighs that:
+//   * w3 dgrad with the SwiGLU backward in its epilogue (25 us of epilogue per 256 x 256 tile) above one round of tiles: x1.16 .. 1.19;
+//   * qkv + RoPE and the SwiGLU forward with at most ~4 rounds of 256 x 256 tiles (M = 16448 / 8192): x1.10 .. 1.13;
+//   * plain bf16 epilogues with K <= 2304 where 256 x 256 tiles fill at most half the chip but 128 x 256 tiles fill >= 3/4 of it
+//     (pixel decoder dgrads M = 8192, N = 768: x1.04 .. 1.15; text-tower c_proj dgrad 2464 x 3072 x 768: x1.24).
+// fp32-residual and GELU epilogues never won (x0.83 .. 1.03).
+static bool use_8h_nt(const GemmArgs& a, int epilogue) {
+  if (a.N % 256 != 0 || a.N < 256 || a.K < 512) return false;
+  const int t256 = cdiv(a.M, 256) * (a.N / 256), t8h = cdiv(a.M, 128) * (a.N / 256);
+  if (epilogue == VTP_EPI_BF16) {
+    if (a.swiglu_pre) return t256 > 256;
+    if (a.rope_pos) return t256 >= 192 && t256 <= 768;
+    return t256 <= 128 && t8h >= 192 && a.K <= 2304;
+  }
+  if (epilogue == VTP_EPI_SWIGLU) return t256 > 768 && t256 <= 1280;
+  return false;
+}
+
 // weight gradients (TN, K = tokens): 8-phase kernel when tiles x splits is one round of the CUs and every K slice keeps >= 16
 // k-tiles (vtp_gemm_tn_splits picks the split factor accordingly)
 static bool use_8p_tn(int M, int N, int K, int splits, const GemmArgs& a) {
@@ -450,6 +479,13 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   if (K >= 4096) return 21;               // long K: pipelined 8-wave 128x128 (DMA issue + fragment prefetch between MFMAs)
   if (epilogue == VTP_EPI_SWIGLU) return 0;     // N = 2H wide: plenty of tiles, 4-wave 128x128
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
+}
+
+// the dispatch of the NT entry points: the measured table above, then the half-size kernel where it wins
+static int pick_cfg_nt(const GemmArgs& a, int epilogue, int splits) {
+  const int cfg = pick_cfg(a.M, a.N, a.K, epilogue, splits);
+  if (g_force_cfg < 0 && splits == 1 && a.a_grp == 0 && use_8h_nt(a, epilogue) && gemm8p_fits(a, false)) return 9;
+  return cfg;
 }
 
 }  // namespace vtp
@@ -519,7 +555,9 @@ extern "C" int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle) {
 // table be pinned by a CPU test (tests/test_host_logic.py) -- the policy is measured per shape and easy to break by an edit.
 extern "C" int vtp_gemm_nt_config(int M, int N, int K, int epilogue) {
   if (M <= 0 || N <= 0 || K <= 0) return -1;
-  int cfg = pick_cfg(M, N, K, epilogue, 1);
+  GemmArgs a{};  // plain epilogue of the given kind (no fused RoPE / SwiGLU backward: those have their own entry points)
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
+  int cfg = pick_cfg_nt(a, epilogue, 1);
   int cs = 1;
   if (g_force_cfg < 0 && epilogue <= VTP_EPI_GELU) cs = combine_splits(M, N, K);
   if (cs > 1) cfg = 8;
@@ -548,7 +586,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   a.k_split = ks;
   splits = (K + ks - 1) / ks;
   hipStream_t s = (hipStream_t)stream;
-  int cfg = pick_cfg(M, N, K, epilogue, splits);
+  int cfg = pick_cfg_nt(a, epilogue, splits);
   // few output tiles, long K (the pixel decoder's and the text tower's dgrads, their K = 2048 .. 4096 projections): the 256 x 256
   // kernel with the K range cut into slices that are combined INSIDE the launch by the last-arriving slice (which then runs the
   // normal epilogue) -- tiles x slices fills the CUs that 30 .. 100 tiles alone leave idle
@@ -589,7 +627,7 @@ extern "C" int vtp_gemm_dgrad_swiglu(const void* A, int lda, const void* WT, int
   a.xcd_swizzle = swz_flags() | 2;  // the fused backward lives in the LDS-staged store path
   a.k_split = (K + 63) / 64 * 64;
   a.swiglu_pre = (const bf16*)x12; a.swiglu_ld = ldx;
-  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg(M, H, K, VTP_EPI_BF16, 1), (hipStream_t)stream);
+  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg_nt(a, VTP_EPI_BF16, 1), (hipStream_t)stream);
 }
 
 // fp8 (e4m3, OCP) forward GEMM (BASELINE config 5): C = alpha * (A8 B8^T) (+ bias, + residual / SwiGLU), A8 [M, K] and B8 [N, K]
@@ -640,7 +678,7 @@ extern "C" int vtp_gemm_qkv_rope(const void* A, int lda, const void* W, int ldb,
   a.xcd_swizzle = swz_flags() | 2;  // the rotation lives in the LDS-staged store path
   a.k_split = (K + 63) / 64 * 64;
   a.rope_pos = rope_pos; a.rope_sin = (const bf16*)rope_sin; a.rope_cos = (const bf16*)rope_cos; a.rope_cols = rope_cols;
-  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg(M, N, K, VTP_EPI_BF16, 1), (hipStream_t)stream);
+  return launch_gemm<EPI_BF16, false>(a, 1, pick_cfg_nt(a, VTP_EPI_BF16, 1), (hipStream_t)stream);
 }
 
 // C[M,N] (f32) = A[K,M]^T * B[K,N]  (A, B bf16 row-major with the reduction dimension K = tokens as rows):

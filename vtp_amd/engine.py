@@ -803,7 +803,8 @@ class Stack:
         # grouped weight gradients: the four dW of block i are ONE launch (split-K combine and bias-gradient column sums inside
         # it), issued at the start of block i - 1's backward so that it overlaps that block's dgrad / attention kernels; the dy
         # operands it reads (dpre, dmid_b, dqkv; dy_b already alternates) are therefore double-buffered by block parity
-        grouped = WGRAD_GROUPED and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks)
+        grouped = WGRAD_GROUPED and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks) \
+            and ops.wgrad_group_fits(M, max(3 * D, 2 * H if vit else H))  # else: per-layer launches (ring-kernel fallback inside)
         par = (lambda i: f".{i & 1}") if grouped else (lambda i: "")
         dh = ws.get("b.dh", (M, H), BF)
         d_o = ws.get("b.do", (M, D), BF)

@@ -151,6 +151,20 @@ def gemm_tn(a, b, c, *, M, N, K, lda, ldb, ldc, ldc2=0, resid=None, epi=EPI_F32,
     _lib.check(rc, "vtp_gemm_tn")
 
 
+def wgrad_group_fits(Ktok: int, max_ld: int) -> bool:
+    """the grouped launch stages its operands with 32-bit byte offsets (k row x leading dimension x 2 B): rows x widest leading
+    dimension must stay below 4 GiB -- otherwise the caller takes the per-layer path, which has the ring-kernel fallback"""
+    return int(Ktok) * int(max_ld) * 2 < (1 << 32)
+
+
+def wgrad_group_splits(ntiles: int, Ktok: int):
+    """split rule of a grouped launch: tiles x splits fills one round of the 256 CUs, every K slice keeps >= 16 k-tiles; returns
+    (k rows per slice, effective slice count) -- the launcher (vtp_gemm_tn_grouped) rounds the same way"""
+    s = max(1, min(256 // ntiles, Ktok // 1024))
+    ks = ((Ktok + s - 1) // s + 63) // 64 * 64
+    return ks, (Ktok + ks - 1) // ks
+
+
 class WgradGroup:
     """The weight gradients of one transformer block as ONE launch (vtp_gemm_tn_grouped): problems dW_g[N_g, K_g] (+)= dy_g^T x_g
     over the same token rows.  add() the problems, finalize() once (the operand buffers are static: the device descriptor table
@@ -175,9 +189,10 @@ class WgradGroup:
         the groups that never run concurrently (one partial-sum / ticket buffer for all of them)."""
         import torch
         assert 1 <= len(self.rows) <= 8
-        s = max(1, min(256 // self.ntiles, self.Ktok // 1024))
-        ks = ((self.Ktok + s - 1) // s + 63) // 64 * 64
-        self.splits = (self.Ktok + ks - 1) // ks
+        if not wgrad_group_fits(self.Ktok, max(max(r[4], r[5]) for r in self.rows)):
+            raise ValueError("WgradGroup: token rows x leading dimension exceed the 32-bit staging offsets of vtp_gemm_tn_grouped; "
+                             "use the per-layer weight-gradient path (linear_bwd without `defer`)")
+        _, self.splits = wgrad_group_splits(self.ntiles, self.Ktok)
         self.table = torch.tensor(self.rows, dtype=torch.int64, device=device)
         if self.splits > 1:
             scratch = {} if scratch is None else scratch
