@@ -15,7 +15,7 @@ oracle runs on the host; the kernels' launch shapes (M, N, K, tails, N = 1025 ti
 import pytest
 import torch
 
-from test_parity_ssl_gpu import DEV, HEAD_KEYS, Case, _compare_grads, _trainer, check
+from test_parity_ssl_gpu import DEV, HEAD_KEYS, LOSS_REL_FLOOR, Case, _compare_grads, _trainer, check
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +67,7 @@ def test_large_512_ssl_only_gradients():
     loss = float(tr.ssl_loss_sum)
     e, e_ref = abs(loss - c.loss["f32"]), max(abs(c.loss["cpu16"] - c.loss["f32"]), abs(c.loss["gpu16"] - c.loss["f32"]))
     print(f"PARITY L512 SSL loss: ours={loss:.6f} oracle fp32={c.loss['f32']:.6f} |err| ours={e:.2e} ref={e_ref:.2e}")
-    assert e <= max(1.25 * e_ref, 2e-4 * abs(c.loss["f32"]))
+    assert e <= max(1.25 * e_ref, LOSS_REL_FLOOR * abs(c.loss["f32"]))
     _compare_grads("L512 SSL-only", dict(c.model.named_parameters()), HEAD_KEYS + TRUNK_KEYS, c.grads_ssl)
 
 

@@ -102,6 +102,15 @@ def load():
         raise RuntimeError(
             f"vtp_amd: {LIB_PATH} not found. The HIP library is mandatory (there is no fallback path): "
             "run `python -c 'import __graft_entry__ as g; g.build()'` or `python vtp_amd/build.py`.")
+    # On a GPU box the HIP runtime must be up BEFORE the library's fat binaries register themselves (dlopen): loading it first
+    # (e.g. __graft_entry__.build() followed by smoke() in one process) left every later launch of ours failing with "no
+    # ROCm-capable device is detected" although torch's own kernels ran (ROCm 7.2, measured round 4).  No GPU: nothing to do.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:  # the ABI / symbol check of tests/test_abi.py does not need torch
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.vtp_abi_version.restype = c_int
     lib.vtp_last_error.restype = c_char_p

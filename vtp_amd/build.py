@@ -28,7 +28,7 @@ def _digest():
     for f in _sources() + hdrs + [os.path.join(ROOT, "include", "vtp_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(f for f in FLAGS if not os.path.isabs(f)).encode())  # not the checkout path: the GPU box must not rebuild
     return h.hexdigest()
 
 
