@@ -76,3 +76,16 @@ def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.load()
+
+
+def test_diagnostics_hooks_are_refused_without_vtp_diag(monkeypatch):
+    """vtp_gemm_debug feeds production kernels process-wide -- anything but 'all off' needs VTP_DIAG=1 (host-only check)"""
+    from vtp_amd import _lib
+    lib = _lib.load()
+    monkeypatch.delenv("VTP_DIAG", raising=False)
+    assert lib.vtp_gemm_debug(None, 0, 0) == 0
+    assert lib.vtp_gemm_debug(None, 0, 100) != 0 and b"VTP_DIAG" in lib.vtp_last_error()
+    assert lib.vtp_gemm_debug(None, 64, 0) != 0
+    monkeypatch.setenv("VTP_DIAG", "1")
+    assert lib.vtp_gemm_debug(None, 0, -5) != 0  # the 'no stores' mode is gone
+    assert lib.vtp_gemm_debug(None, 64, 0) == 0 and lib.vtp_gemm_debug(None, 0, 0) == 0

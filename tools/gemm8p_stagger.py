@@ -4,6 +4,8 @@ step across the chip -- MFMA idle while every CU stores, HBM idle while every CU
 CUs interleaves the two phases.
 Usage (GPU box): python tools/gemm8p_stagger.py > gpurun_out/gemm8p_stagger.log"""
 import os
+
+os.environ.setdefault("VTP_DIAG", "1")  # the library accepts its diagnostics hooks only in a process that asked for them
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

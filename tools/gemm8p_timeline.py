@@ -3,6 +3,8 @@
 same launch with the persistent grid capped to 32 workgroups (an eighth of the chip: is the epilogue bound per CU or chip-wide?).
 Usage (GPU box): python tools/gemm8p_timeline.py > gpurun_out/gemm8p_timeline.log"""
 import os
+
+os.environ.setdefault("VTP_DIAG", "1")  # the library accepts its diagnostics hooks only in a process that asked for them
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -116,8 +118,7 @@ def main():
         for grid in (0, 32):
             Mg = M if grid == 0 else (M // 8 // 256) * 256  # an eighth of the rows on an eighth of the chip
             run(lib, tag, Mg, N, K, epi, grid, g)
-        if epi == ops.EPI_BF16:
-            run(lib, tag, M, N, K, epi, 0, g, delay=-1)
+        # (round 3 also ran a NO-STORES build here -- delay = -1: -1 % -- that kernel mode was removed in round 4)
     lib.vtp_set_gemm_tuning(-1, 3)
 
 

@@ -3,6 +3,8 @@ sums) against the per-layer path it replaces (split-K TN GEMM into slabs + reduc
 chip, at the token counts of the step (34 144 trunk, 8 192 decoder, 2 464 text); plus the in-kernel stamps of the grouped launch
 (k loop / combine + epilogue per workgroup).  Usage (GPU box): python tools/wgrad_group_bench.py > gpurun_out/wgrad_group.log"""
 import os
+
+os.environ.setdefault("VTP_DIAG", "1")  # the library accepts its diagnostics hooks only in a process that asked for them
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -559,7 +559,7 @@ extern "C" int vtp_gemm_nt_config(int M, int N, int K, int epilogue) {
   a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K;
   int cfg = pick_cfg_nt(a, epilogue, 1);
   int cs = 1;
-  if (g_force_cfg < 0 && epilogue <= VTP_EPI_GELU) cs = combine_splits(M, N, K);
+  if (g_force_cfg < 0 && epilogue <= VTP_EPI_GELU && gemm8p_fits(a, false)) cs = combine_splits(M, N, K);  // as vtp_gemm_nt decides
   if (cs > 1) cfg = 8;
   return cfg | (cs > 1 ? cs << 8 : 0);
 }

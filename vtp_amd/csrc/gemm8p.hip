@@ -699,6 +699,19 @@ extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int
 // written by the 8-phase kernel (null: off); grid_limit caps its persistent grid (0: every CU); delay_ticks > 0 starts every second
 // workgroup of an XCD that many 10-ns ticks late (is the chip's lock-step what serialises k loops and epilogue stores?)
 extern "C" int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks) {
+  // process-global hooks of PRODUCTION kernels: anything but "all off" is accepted only in a process that asked for
+  // diagnostics (VTP_DIAG=1 in its environment: the tools/ scripts set it); the "no stores" mode of round 3 is gone.  The stamp
+  // buffer must hold (workgroups of the launch + 256) x 64 u64 values -- the kernels index it by workgroup and do not check.
+  const bool off = timing == nullptr && grid_limit == 0 && delay_ticks == 0;
+  const char* diag = getenv("VTP_DIAG");
+  if (!off && !(diag && diag[0] == '1')) {
+    vtp::set_error("vtp_gemm_debug: diagnostics hooks need VTP_DIAG=1 in the environment");
+    return VTP_ERR_ARG;
+  }
+  if (delay_ticks < 0 || grid_limit < 0) {
+    vtp::set_error("vtp_gemm_debug: negative grid limit / delay");
+    return VTP_ERR_ARG;
+  }
   vtp::g_p8_timing = (unsigned long long*)timing;
   vtp::g_p8_grid = grid_limit;
   vtp::g_p8_delay = delay_ticks;

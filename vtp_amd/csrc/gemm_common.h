@@ -50,8 +50,7 @@ struct GemmArgs {
   int* ticket;
   // diagnostics (vtp_gemm_debug): per workgroup and tile, s_memrealtime stamps {tile start, k loop done, epilogue issued}; null = off
   unsigned long long* timing;
-  int dbg_delay;  // diagnostics: > 0: every second workgroup (per XCD) starts this many 10-ns ticks late (lock-step experiments);
-                  // < 0: the bf16 epilogue computes everything but issues no global store (is the next k loop waiting for them?)
+  int dbg_delay;  // diagnostics: > 0: every second workgroup (per XCD) starts this many 10-ns ticks late (lock-step experiments)
 };
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
@@ -201,7 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             }
             continue;
           }
-          if (m < p.M && n < p.N && p.dbg_delay >= 0) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
+          if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
         }
       }
     }
