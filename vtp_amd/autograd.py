@@ -251,10 +251,11 @@ def _ws(model):
 
 class HeadLinear(torch.autograd.Function):
     """y f32 [R, N] = alpha * bf16(x) W^T for a bias-free projection held by the engine (`lin`: engine.Lin with bf16 W / W^T copies
-    and the flat-gradient view); backward: dx = alpha * dy W, dW += alpha * dy^T x accumulated into the flat gradient buffer."""
+    and the flat-gradient view); backward: dx = alpha * dy W, dW += alpha * dy^T x accumulated into the flat gradient buffer --
+    unless the weight is frozen (`wgrad` False: its nn.Parameter does not require a gradient; the GEMM is skipped)."""
 
     @staticmethod
-    def forward(ctx, x, anchor_, model, lin, alpha):
+    def forward(ctx, x, anchor_, model, lin, alpha, wgrad=True):
         st = model._fresh()
         st.sync_grad_views()
         R, K = x.shape
@@ -263,7 +264,7 @@ class HeadLinear(torch.autograd.Function):
         ops.cast_f32_bf16(x.contiguous().float(), x_b, R * K)
         y = torch.empty(R, lin.N, dtype=F32, device=x.device)
         ops.gemm_nt(x_b, lin.w, y, M=R, N=lin.N, K=K, epi=ops.EPI_F32, alpha=alpha)
-        ctx.model, ctx.lin, ctx.alpha, ctx.x_b = model, lin, alpha, x_b
+        ctx.model, ctx.lin, ctx.alpha, ctx.x_b, ctx.wgrad = model, lin, alpha, x_b, bool(wgrad)
         return y
 
     @staticmethod
@@ -275,10 +276,11 @@ class HeadLinear(torch.autograd.Function):
         ops.cast_f32_bf16(dy.contiguous().float(), dy_b, R * lin.N)
         dx = torch.empty(R, K, dtype=F32, device=dy.device)
         ops.gemm_nt(dy_b, lin.wT, dx, M=R, N=K, K=lin.N, epi=ops.EPI_F32, alpha=ctx.alpha)
-        if ctx.alpha != 1.0:  # dW += alpha * dy^T x: fold alpha into dy (one more rounding of a [R, N] matrix)
-            ops.cast_f32_bf16((dy * ctx.alpha).contiguous().float(), dy_b, R * lin.N)
-        ops.gemm_tn(dy_b, x_b, lin.gw, M=lin.N, N=K, K=R, lda=lin.N, ldb=K, ldc=K, resid=lin.gw, epi=ops.EPI_F32)
-        return dx, None, None, None, None
+        if ctx.wgrad:
+            if ctx.alpha != 1.0:  # dW += alpha * dy^T x: fold alpha into dy (one more rounding of a [R, N] matrix)
+                ops.cast_f32_bf16((dy * ctx.alpha).contiguous().float(), dy_b, R * lin.N)
+            ops.gemm_tn(dy_b, x_b, lin.gw, M=lin.N, N=K, K=R, lda=lin.N, ldb=K, ldc=K, resid=lin.gw, epi=ops.EPI_F32)
+        return dx, None, None, None, None, None
 
 
 class SumTokens(torch.autograd.Function):

@@ -359,6 +359,7 @@ static int swz_flags() { return g_xcd_swizzle; }
 int launch_gemm8p_nt(const GemmArgs& a, int epi, int splits, hipStream_t s);
 int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s);
 bool gemm8p_fits(const GemmArgs& a, bool trans);
+bool gemm8p_combine_ready(hipStream_t s);
 // gemm8h.hip: 128x256 half-size variant, two workgroups per CU (cfg 9; NT, one K slice)
 int launch_gemm8h_nt(const GemmArgs& a, int epi, hipStream_t s);
 
@@ -592,6 +593,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   // normal epilogue) -- tiles x slices fills the CUs that 30 .. 100 tiles alone leave idle
   int cs = 1;
   if (splits == 1 && g_force_cfg < 0 && epilogue <= VTP_EPI_GELU && gemm8p_fits(a, false)) cs = combine_splits(M, N, K);
+  if (cs > 1 && !gemm8p_combine_ready(s)) cs = 1;  // no scratch for this stream: the unsplit launch (slower, never wrong)
   if (cs > 1) {
     a.k_split = ((K + cs - 1) / cs + 63) / 64 * 64;
     cs = (K + a.k_split - 1) / a.k_split;

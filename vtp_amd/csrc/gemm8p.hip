@@ -558,7 +558,8 @@ static int g_p8_grid = 0, g_p8_delay = 0;
 // text tower beside the decoder) must not.  A pool of 8 slots (256 tile-slices x 256 KiB + tickets each) is allocated at the FIRST
 // combine launch of the process -- an eager one: the trainers warm up eagerly before any stream capture, and allocating under
 // capture is not possible -- and every stream handle is bound to a slot the first time it is seen (no allocation then, so a
-// capture stream that shows up later is fine).
+// capture stream that shows up later is fine).  No pool (allocation failed, first use under capture) or no free slot (more than 8
+// streams): the dispatcher (vtp_gemm_nt) launches the shape without the K split.
 struct CombineScratch {
   float* part = nullptr;
   int* ticket = nullptr;
@@ -568,21 +569,40 @@ static CombineScratch* combine_scratch(hipStream_t s) {
   static std::mutex mu;
   static CombineScratch pool[SLOTS];
   static std::unordered_map<hipStream_t, int> slot_of;
-  static bool ready = false;
+  static bool ready = false, failed = false;
   std::lock_guard<std::mutex> lock(mu);
   if (!ready) {
+    if (failed) return nullptr;  // one attempt per process: callers fall back to the unsplit launch
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;  // no allocation under capture
     float* part = nullptr;
     int* ticket = nullptr;
-    if (hipMalloc((void**)&part, (size_t)SLOTS * 256 * 65536 * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&part, (size_t)SLOTS * 256 * 65536 * sizeof(float)) != hipSuccess) {
+      failed = true;
+      return nullptr;
+    }
     if (hipMalloc((void**)&ticket, (size_t)SLOTS * 1024 * sizeof(int)) != hipSuccess ||
-        hipMemset(ticket, 0, (size_t)SLOTS * 1024 * sizeof(int)) != hipSuccess) return nullptr;
+        hipMemset(ticket, 0, (size_t)SLOTS * 1024 * sizeof(int)) != hipSuccess) {
+      (void)hipFree(part);
+      if (ticket) (void)hipFree(ticket);
+      failed = true;
+      return nullptr;
+    }
     for (int i = 0; i < SLOTS; ++i) pool[i] = CombineScratch{part + (size_t)i * 256 * 65536, ticket + i * 1024};
     ready = true;
   }
   auto it = slot_of.find(s);
-  if (it == slot_of.end()) it = slot_of.emplace(s, (int)(slot_of.size() % SLOTS)).first;
+  if (it == slot_of.end()) {
+    // a 9th distinct stream would have to share partial sums and tickets with a stream that may run concurrently: refuse
+    if ((int)slot_of.size() >= SLOTS) return nullptr;
+    it = slot_of.emplace(s, (int)slot_of.size()).first;
+  }
   return &pool[it->second];
 }
+
+// may this stream use the in-launch split-K combine?  (allocates the scratch pool at the first call outside stream capture; false:
+// the dispatcher launches the shape unsplit)
+bool gemm8p_combine_ready(hipStream_t s) { return combine_scratch(s) != nullptr; }
 
 template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
 static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {

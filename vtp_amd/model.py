@@ -457,8 +457,8 @@ class VTPModel(nn.Module):
                 else:  # mean over the patch tokens: the sum here, 1 / hw in the next projection (linear maps commute with the mean)
                     feat, scale = ag.SumTokens.apply(tokens[:, 1:]), 1.0 / (tokens.shape[1] - 1)
                 if not c.vision_bottleneck_ae_only and self._trunk.bott is not None:
-                    feat, scale = ag.HeadLinear.apply(feat, a, self, self._trunk.bott, scale), 1.0
-                feat = ag.HeadLinear.apply(feat, a, self, self._vproj, scale)
+                    feat, scale = ag.HeadLinear.apply(feat, a, self, self._trunk.bott, scale, self.trunk.feature_bottleneck.weight.requires_grad), 1.0
+                feat = ag.HeadLinear.apply(feat, a, self, self._vproj, scale, self.visual_proj.weight.requires_grad)
                 return ag.L2Normalize.apply(feat) if normalize else feat
         return self._clip_image_nograd(image, normalize)
 
