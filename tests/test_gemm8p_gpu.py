@@ -261,3 +261,39 @@ def test_in_launch_split_k_combine(M, N, K, epi_name):
             o.gemm_nt(a, w, out, c2=pre, bias=bias, epi=o.EPI_GELU)
             check(pre, ref, f"combine gelu pre {M}x{N}x{K}")
             check(out, F.gelu(bf(ref).float()), f"combine gelu {M}x{N}x{K}", scale=4e-3)
+
+
+def test_split_k_combine_run_to_run_bound():
+    """The in-launch split-K combine adds the other slices' partial tiles to the registers of whichever slice arrives LAST, in slice
+    order around it (csrc/gemm8p.hip): with TWO slices that is a commutative fp32 add -- every launch gives the same bits; with THREE
+    the association depends on the arrival order, so weight gradients may differ from run to run by fp32 rounding of the partial
+    sums.  Stated bound: |run_i - run_0| <= 4 * 2^-24 * (|dy|^T |x|) element-wise, i.e. a few fp32 ulps of the
+    sum of absolute products -- never more than the error of ANY fixed summation order."""
+    o = ops()
+    Ktok, D, H = 34144, 768, 768
+    g = torch.Generator(device=DEV).manual_seed(77)
+    dy = bf(torch.randn(Ktok, D, device=DEV, generator=g))
+    x = bf(torch.randn(Ktok, H, device=DEV, generator=g))
+    bound = 4.0 * 2.0 ** -24 * (dy.float().abs().T @ x.float().abs())
+    for forced, must_be_identical in ((2, True), (3, False)):
+        outs = []
+        for rep in range(8):
+            out = torch.full((D * H,), float("nan"), device=DEV)
+            grp = o.WgradGroup(Ktok)
+            grp.add(dy, x, out, None, D, H, 0, accumulate=False)
+            grp.finalize(DEV, {})
+            grp.splits = forced
+            grp.part = torch.empty(grp.ntiles * forced * 65536, device=DEV)
+            grp.ticket = torch.zeros(max(grp.ntiles, 256), dtype=torch.int32, device=DEV)
+            junk = torch.empty(32 << 20, device=DEV).normal_()  # perturb the arrival order between repetitions
+            grp.launch()
+            del junk
+            outs.append(out.view(D, H).clone())
+        check(outs[0], dy.float().T @ x.float(), f"grouped split-{forced}", bf16_out=False, scale=1e-4)
+        diffs = [(t - outs[0]).abs() for t in outs[1:]]
+        worst = max(float((d / bound).max()) for d in diffs)
+        nbits = sum(int((d > 0).sum()) for d in diffs)
+        print(f"split-K combine, {forced} slices: {nbits} elements differ over 7 repetitions, worst |diff| / bound = {worst:.3f}")
+        assert all(bool((d <= bound).all()) for d in diffs), f"{forced} slices: run-to-run difference above the stated bound"
+        if must_be_identical:
+            assert nbits == 0, "two slices: the combine is a commutative add and must be bit-reproducible"
