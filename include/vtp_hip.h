@@ -151,6 +151,9 @@ int vtp_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
 /* im2col for the 16x16/s16 patch-embed conv (embeddings.py:58,64-69): img f32 [B,3,H,W] -> patches bf16 [B*h*w, 768],
  * K order (c, ky, kx), token order (y, x). */
 int vtp_im2col16(const float* img, void* patches, int B, int H, int W, void* stream);
+/* gradient w.r.t. the input image of PatchEmbed (embeddings.py:61-70 backward; the reference's autograd returns it when the image
+ * requires grad): d_patches f32 [B*hw, 768] (= d_tokens[patch rows] W_pe, K order (c, ky, kx)) folded back to d_img f32 [B,3,H,W] */
+int vtp_col2im16(const float* dpatches, float* dimg, int B, int H, int W, void* stream);
 /* col2im adjoint is not needed: the image is data (no input gradient). */
 
 /* rows [B, N, D] f32: write row 0 of every batch element = cls[D] (vision_transformer.py:198,210-217);

@@ -267,14 +267,20 @@ def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True) -> 
     return x + F.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
 
 
-def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True) -> Tensor:
-    """VTPModel.get_clip_text_feature -- modeling_vtp.py:278-310; argmax (EOT) pooling
-    text_transformer.py:213-228."""
+def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True, pool_type: str = "argmax",
+                      causal: bool = True) -> Tensor:
+    """VTPModel.get_clip_text_feature -- modeling_vtp.py:278-310; text_global_pool text_transformer.py:213-228 (argmax = EOT | first
+    | last); causal = not text_no_causal_mask (text_transformer.py:285-288)."""
     x = F.embedding(text, sd["token_embedding.weight"]) + sd["positional_embedding"]
     for i in range(_depth(sd, "text_transformer.resblocks.")):
-        x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads)
+        x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads, causal=causal)
     x = layernorm(x, sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
-    x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
+    if pool_type == "first":
+        x = x[:, 0]
+    elif pool_type == "last":
+        x = x[:, -1]
+    else:
+        x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
     x = x @ sd["text_projection"]
     return F.normalize(x, dim=-1) if normalize else x
 

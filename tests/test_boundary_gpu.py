@@ -323,3 +323,45 @@ def test_patch_model_rebinds_a_reference_style_instance(golden, golden_sd):
     loss = (ref.get_latents_decoded_images(ref.get_reconstruction_latents(img)) - img).abs().mean()
     loss.backward()  # differentiable through the patched object
     assert float(dict(ref.named_parameters())["trunk.blocks.0.attn.qkv.weight"].grad.abs().sum()) > 0
+
+
+def test_gradient_with_respect_to_the_input_image(golden, golden_sd):
+    """VERDICT r3 'missing' item 5: the reference's autograd delivers d loss / d image when the image requires grad (PatchEmbed is an
+    nn.Conv2d, embeddings.py:61-70).  Here: d(L1 reconstruction + a CLIP-feature functional) / d image through EncodeLatents /
+    TrunkTokens (dgrad of the patch-embed GEMM + vtp_col2im16) against the oracle's autograd in fp32; E_ref = the oracle under CPU
+    bf16 autocast; bar E_ours <= 1.5 E_ref (tiny model)."""
+    from oracle import vtp_oracle as O
+    img0, tgt = golden["in.image"], golden["in.image"].flip(0)
+
+    def oracle_grad(autocast):
+        x = img0.clone().requires_grad_(True)
+        import contextlib
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+        with ctx:
+            lat = O.reconstruction_latents(golden_sd, x, 2)
+            rec = O.decoder_forward(golden_sd, lat, 2)
+            feat = O.clip_image_feature(golden_sd, x, 2, normalize=True)
+            loss = (rec.float() - tgt).abs().mean() + feat.float()[:, :7].sum() * 0.1
+        loss.backward()
+        return x.grad.clone(), float(loss)
+
+    g_ref, l_ref = oracle_grad(False)
+    g_16, _ = oracle_grad(True)
+    m = _tiny(golden_sd)
+    m.train()
+    m.zero_grad()
+    x = img0.clone().to(DEV).requires_grad_(True)
+    rec = m(image=x, forward_type="rec")["reconstructed_image"]
+    feat = m.get_clip_image_feature(x, normalize=True)
+    loss = (rec - tgt.to(DEV)).abs().mean() + feat[:, :7].sum() * 0.1
+    loss.backward()
+    torch.cuda.synchronize()
+    assert x.grad is not None and x.grad.shape == img0.shape and x.grad.dtype == torch.float32
+    e, e_ref = relF(x.grad, g_ref), relF(g_16, g_ref)
+    print(f"d loss / d image: loss ours {float(loss):.5f} oracle {l_ref:.5f}; E_ours={e:.3e} E_ref={e_ref:.3e} ratio={e / e_ref:.2f}")
+    assert e <= 1.5 * e_ref
+    # without requires_grad on the image nothing is computed or returned
+    m.zero_grad()
+    y = img0.clone().to(DEV)
+    m(image=y, forward_type="rec")["reconstructed_image"].mean().backward()
+    assert y.grad is None

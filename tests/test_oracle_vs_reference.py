@@ -253,3 +253,20 @@ def test_clip_image_feature_variants_match_reference(clip_feat, ae_only):
         t = O.clip_text_feature(sd, text, 2)
         lo = sd["logit_scale"].exp() * f @ t.T + sd["logit_bias"]
         torch.testing.assert_close(lo, li, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("pool,no_causal", [("first", False), ("last", False), ("argmax", True), ("last", True)])
+def test_text_pooling_and_mask_variants_match_reference(pool, no_causal):
+    """text_global_pool first / last and no_causal_mask (text_transformer.py:213-228,285-288) -- the oracle branch behind the
+    round-4 text-tower variants, against the real class"""
+    from oracle.ref_stubs import TINY, load_reference
+    ref = load_reference()
+    torch.manual_seed(5)
+    m = ref.VTPModel(ref.VTPConfig(**dict(TINY, text_pool_type=pool, text_no_causal_mask=no_causal))).eval()
+    sd = m.state_dict()
+    text = torch.randint(1, 500, (3, 16))
+    text[:, 9] = 511
+    with torch.no_grad():
+        want = m.get_clip_text_feature(text)
+        got = O.clip_text_feature(sd, text, 2, pool_type=pool, causal=not no_causal)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)

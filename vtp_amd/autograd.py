@@ -90,6 +90,7 @@ class TrunkTokens(torch.autograd.Function):
         ctx.ticket = _flight(model).take(key)
         xnf = model._trunk.forward(img, train=True, tag=tag)
         ctx.model, ctx.key, ctx.tctx, ctx.shape = model, key, model._trunk.ctx(), (B, (H // 16) * (W // 16) + 1)
+        ctx.img_dtype = image.dtype
         return xnf.float().view(B, ctx.shape[1], -1).clone()
 
     @staticmethod
@@ -99,8 +100,9 @@ class TrunkTokens(torch.autograd.Function):
         model._store.sync_grad_views()
         d_xnf = tr.d_xnf_buffer(ctx.tctx)
         d_xnf.copy_(d_tokens.reshape(d_xnf.shape))  # f32 -> bf16, every row written
-        _drain(tr.backward(None, ctx=ctx.tctx))
-        return None, None, None, None
+        want = ctx.needs_input_grad[0]  # the image itself requires grad (the reference's autograd would deliver d/d image)
+        _drain(tr.backward(None, ctx=ctx.tctx, want_dimg=want))
+        return (ctx.tctx.d_img[0].to(ctx.img_dtype) if want else None), None, None, None
 
 
 class EncodeLatents(torch.autograd.Function):
@@ -118,6 +120,7 @@ class EncodeLatents(torch.autograd.Function):
         model._trunk.forward(img, train=True, tag=tag)
         lat = model._trunk.latents(out_f32=True)
         ctx.model, ctx.key, ctx.tctx, ctx.dims = model, key, model._trunk.ctx(), (B, h, w)
+        ctx.img_dtype = image.dtype
         return lat.view(B, h * w, -1).transpose(1, 2).reshape(B, -1, h, w).clone()
 
     @staticmethod
@@ -129,8 +132,9 @@ class EncodeLatents(torch.autograd.Function):
         d_tok = d_lat.reshape(B, -1, h * w).transpose(1, 2).to(BF).contiguous().view(B * h * w, -1)
         d_xnf = tr.d_xnf_buffer(ctx.tctx)
         d_xnf.zero_()  # the bottleneck dgrad writes the patch rows only: the cls rows carry no gradient on this path
-        _drain(tr.backward(d_tok, ctx=ctx.tctx))
-        return None, None, None, None
+        want = ctx.needs_input_grad[0]
+        _drain(tr.backward(d_tok, ctx=ctx.tctx, want_dimg=want))
+        return (ctx.tctx.d_img[0].to(ctx.img_dtype) if want else None), None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------- pixel decoder

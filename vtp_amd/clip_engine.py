@@ -22,6 +22,10 @@ class TextEngine:
         self.Dout = cfg.text_embed_dim  # output_dim = text_embed_dim (modeling_vtp.py:150)
         self.stack = Stack(store, "text_transformer.resblocks.", self.depth, self.D, self.heads, self.H, "layernorm",
                            style="text")
+        # text_transformer.py:285-288: no_causal_mask drops the additive causal mask (full attention over the T tokens);
+        # text_global_pool (:213-228): the pooled row is the first / last token or the arg-max id (EOT) of every caption
+        self.stack.causal = not cfg.text_no_causal_mask
+        self.pool = cfg.text_pool_type
         # text_projection is stored [width, output_dim] and applied as x @ P (modeling_vtp.py:308): as a Lin with
         # N = width, K = output_dim its bf16 copy `w` is P and `wT` is P^T (the K-contiguous operand of the forward GEMM)
         self.proj = store.lin("text_projection", None, self.D, self.Dout)
@@ -41,6 +45,8 @@ class TextEngine:
         x0 = ws.get("x0", (B * T, D), F32)
         eot = ws.get("eot", (B,), I32)
         ops.embed_tokens(ids, st.p("token_embedding.weight"), st.p("positional_embedding"), x0, eot, B, T, D)
+        if self.pool != "argmax":  # the kernel wrote the arg-max position of every row; 'first' / 'last' pool a fixed position
+            eot.fill_(0 if self.pool == "first" else T - 1)
         xl = self.stack.forward(ws, x0, B, T, None, 0, train)
         pooled = ws.get("pooled", (B, D), F32)
         ops.gather_rows(xl, eot, pooled, B, T, D)  # ln_final is row-wise: pool first, normalise B rows instead of B*T

@@ -76,8 +76,9 @@ class VTPConfig:
         need(self.vision_norm_layer in ("rmsnorm", "layernorm"), "vision_norm_layer must be rmsnorm|layernorm")
         need(self.decoder_norm_layer in ("rmsnorm", "layernorm"), "decoder_norm_layer must be rmsnorm|layernorm")
         need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
-        need(not self.text_embed_cls and self.text_pool_type == "argmax" and not self.text_no_causal_mask,
-             "text tower: only the causal / argmax-pooled CLIP configuration is implemented")
+        need(not self.text_embed_cls, "text tower: embed_cls (an appended class embedding with its padding mask) is not implemented")
+        need(self.text_pool_type in ("argmax", "first", "last"),
+             "text_pool_type must be argmax | first | last ('none' returns per-token features: not implemented)")
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
         need(not self.text_quick_gelu, "quick_gelu is not implemented")
         need(self.text_ls_init_value is None, "LayerScale in the text tower (text_ls_init_value) is not implemented")

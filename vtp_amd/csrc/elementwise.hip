@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
   }
 }
 
+// inverse of im2col16 for the gradient w.r.t. the input image (k = s = 16: patches do not overlap, so the fold is a permutation):
+// d_img[b, c, 16y + ky, 16x + 0..15] = d_patches[token (b, y, x), c*256 + ky*16 + 0..15]
+__global__ __launch_bounds__(256) void col2im16_kernel(const float* __restrict__ dpatches, float* __restrict__ dimg, int B, int H, int W) {
+  const int h = H / 16, w = W / 16;
+  const long total = (long)B * h * w * 48;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    const int ck = (int)(idx % 48);
+    const long tok = idx / 48;
+    const int c = ck / 16, ky = ck % 16;
+    const int x = (int)(tok % w);
+    const int y = (int)((tok / w) % h);
+    const long b = tok / ((long)w * h);
+    const float* src = dpatches + tok * 768 + c * 256 + ky * 16;
+    float* dst = dimg + ((b * 3 + c) * H + (y * 16 + ky)) * (long)W + x * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(dst + 4 * i) = *(const f32x4*)(src + 4 * i);
+  }
+}
+
 // PixelShuffle(16) of the token-major decoder output (+ optional fused L1 loss / gradient).
 template <int MODE>  // 0: write f32 image; 1: L1 loss + dt; 2: dt = un-shuffled image gradient (`img` holds d_img)
 __global__ __launch_bounds__(256) void shuffle16_kernel(const bf16* __restrict__ t, float* __restrict__ img,
@@ -537,6 +556,14 @@ extern "C" int vtp_im2col16(const float* img, void* patches, int B, int H, int W
   const long items = (long)B * (H / 16) * (W / 16) * 48;
   hipLaunchKernelGGL(im2col16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, B, H, W);
   return check_launch("im2col16");
+}
+
+extern "C" int vtp_col2im16(const float* dpatches, float* dimg, int B, int H, int W, void* stream) {
+  VTP_REQUIRE(dpatches && dimg, "vtp_col2im16: null pointer");
+  VTP_REQUIRE(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "vtp_col2im16: H and W must be positive multiples of 16");
+  const long items = (long)B * (H / 16) * (W / 16) * 48;
+  hipLaunchKernelGGL(col2im16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, dpatches, dimg, B, H, W);
+  return check_launch("col2im16");
 }
 
 extern "C" int vtp_assemble_tokens(float* x, const float* cls, const float* mask_token, const unsigned char* masks,

@@ -931,7 +931,7 @@ class TrunkEngine:
         self.kind = ops.NORM_RMS if cfg.vision_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
         self.periods = periods.detach().to("cpu")  # host copy: rope_tables must not touch the device during graph capture
-        self.pe = store.lin(self.prefix + "patch_embed.proj.weight", self.prefix + "patch_embed.proj.bias", self.D, 768, need_T=False)
+        self.pe = store.lin(self.prefix + "patch_embed.proj.weight", self.prefix + "patch_embed.proj.bias", self.D, 768)  # W^T: the input-image gradient
         self.stack = Stack(store, self.prefix + "blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
         self.bott_dim = cfg.vision_feature_bottleneck
         self.bott = store.lin(self.prefix + "feature_bottleneck.weight", None, self.bott_dim, self.D) \
@@ -1011,9 +1011,11 @@ class TrunkEngine:
         c = self._ctx if ctx is None else ctx
         return c.ws.get("b.d_xnf", (c.M, self.D), BF, zero=True)
 
-    def backward(self, d_lat: Optional[torch.Tensor], ctx=None, lat_seg: int = 0):
+    def backward(self, d_lat: Optional[torch.Tensor], ctx=None, lat_seg: int = 0, want_dimg: bool = False):
         """d_lat: bf16 [B*hw, 64] grad of latents(seg=lat_seg), or None.  Accumulates every trunk parameter gradient into
-        store.flat_g.  Generator (see Stack.backward): yields "tail", then ("block", i) per block."""
+        store.flat_g.  Generator (see Stack.backward): yields "tail", then ("block", i) per block.
+        want_dimg: also form the gradient w.r.t. the input images (PatchEmbed backward, embeddings.py:61-70: d_tokens[patch rows]
+        W_pe folded back to pixels) -- ctx.d_img[i] f32 [B_i,3,H_i,W_i] per item; masked patches get zero (they never saw the pixels)."""
         st = self.store
         if ctx is not None:
             self._ctx = ctx
@@ -1046,6 +1048,12 @@ class TrunkEngine:
             linear_bwd(ws, "pe", self.pe, d_sb, c.patches[g.prow0:g.prow0 + g.B * g.hw], g.B * g.hw, None, need_dx=False,
                        dy_remap=(g.hw, 1))
             ops.strided_rowsum(d_s, g.N * D, st.g(self.prefix + "cls_token"), g.B, D)
+            if want_dimg:
+                dpt = ws.get(f"b.dpatch{g.prow0}", (g.B * g.hw, 768), F32)
+                ops.gemm_nt(d_sb, self.pe.wT, dpt, M=g.B * g.hw, N=768, K=D, epi=EPI_F32, a_remap=(g.hw, 1))
+                dimg = torch.empty(g.B, 3, g.h * 16, g.w * 16, dtype=F32, device=st.device)
+                ops.col2im16(dpt, dimg, g.B, g.h * 16, g.w * 16)
+                c.__dict__.setdefault("d_img", {})[g.row0] = dimg
         OVERLAP.join()
 
 

@@ -78,6 +78,11 @@ def im2col16(img, patches, B, H, W):
     _lib.check(_lib_().vtp_im2col16(_p(img), _p(patches), B, H, W, _s()), "vtp_im2col16")
 
 
+def col2im16(dpatches, dimg, B, H, W):
+    """d_img f32 [B,3,H,W] <- d_patches f32 [B*hw, 768] (inverse of im2col16: the PatchEmbed input gradient)"""
+    _lib.check(_lib_().vtp_col2im16(_p(dpatches), _p(dimg), B, H, W, _s()), "vtp_col2im16")
+
+
 def assemble_tokens(x, cls, mask_token, masks, B, N, D):
     _lib.check(_lib_().vtp_assemble_tokens(_p(x), _p(cls), _p(mask_token), _p(masks), B, N, D, _s()), "vtp_assemble_tokens")
 
