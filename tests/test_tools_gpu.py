@@ -40,10 +40,12 @@ def test_eval_tools_plumbing_on_the_hip_model(golden_sd):
         e, e_ref = relF(ours[k], ref), relF(noisy[k], ref)
         print(f"TOOLS {k}: E_ours={e:.3e} E_ref={e_ref:.3e} ratio={e / e_ref:.2f}")
         assert ours[k].shape == ref.shape and e <= 1.5 * e_ref, (k, e, e_ref)
-    for k in ("rec.psnr", "lp.losses"):  # a few scalars each: largest deviation against the reference's own
+    # a few scalars each (PSNR in dB per image, summed cross-entropy per probe step): largest deviation against the reference's own
+    # bf16 deviation, slack 2 (single draws) -- and never asked to agree beyond what the tools print (PSNR :.2f, loss :.3g)
+    for k, printed in (("rec.psnr", 5e-3), ("lp.losses", 5e-4)):
         ref = tg["out." + k]
         e, e_ref = float((ours[k] - ref).abs().max()), float((noisy[k].float() - ref).abs().max())
         print(f"TOOLS {k}: max|err| ours={e:.3e} ref={e_ref:.3e}  values ours={[round(float(v), 4) for v in ours[k]]}")
-        assert e <= 2.0 * e_ref + 1e-6, (k, e, e_ref)
+        assert e <= max(2.0 * e_ref, printed), (k, e, e_ref)
     # top-1 / top-5 of 8 random images on a random-init model are ties broken by bf16 noise: reported, compared only through the logits
     print(f"TOOLS zero-shot top1/top5: ours={ours['zs.top'].tolist()} reference={tg['out.zs.top'].tolist()} oracle-bf16={noisy['zs.top'].tolist()}")

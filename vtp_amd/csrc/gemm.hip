@@ -485,7 +485,8 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
 // the dispatch of the NT entry points: the measured table above, then the half-size kernel where it wins
 static int pick_cfg_nt(const GemmArgs& a, int epilogue, int splits) {
   const int cfg = pick_cfg(a.M, a.N, a.K, epilogue, splits);
-  if (g_force_cfg < 0 && splits == 1 && a.a_grp == 0 && use_8h_nt(a, epilogue) && gemm8p_fits(a, false)) return 9;
+  static const bool use_8h = [] { const char* e = getenv("VTP_GEMM8H"); return !(e && e[0] == '0'); }();  // VTP_GEMM8H=0: same-box A/B of the step
+  if (use_8h && g_force_cfg < 0 && splits == 1 && a.a_grp == 0 && use_8h_nt(a, epilogue) && gemm8p_fits(a, false)) return 9;
   return cfg;
 }
 
