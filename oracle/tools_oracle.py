@@ -186,32 +186,43 @@ def probe_train_steps(feature_model, classifiers: Dict[str, nn.Module], batches,
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return losses
 
 
 # ------------------------------------------------------------------------------------------------ the oracle behind the reference's method surface
 class OracleModel:
-    """oracle/vtp_oracle.py's functions behind the method names the tools call (fp32 on CPU, or under a caller's autocast) -- what
-    the restated plumbing runs on where neither the reference tree nor a GPU is available, and the source of E_ref in the GPU test."""
+    """oracle/vtp_oracle.py's functions behind the method names the tools call (fp32 on CPU; with autocast_dtype every MODEL call runs
+    under torch.autocast -- the tools' own arithmetic (classifier training, metrics) stays outside, as in the reference tools where the
+    autocast context wraps the model call only) -- what the restated plumbing runs on where neither the reference tree nor a GPU is
+    available, and the source of E_ref in the GPU test."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], vis_heads: int, dec_heads: int, txt_heads: int):
-        self.sd, self.hv, self.hd, self.ht = sd, vis_heads, dec_heads, txt_heads
+    def __init__(self, sd: Dict[str, torch.Tensor], vis_heads: int, dec_heads: int, txt_heads: int, autocast_dtype=None):
+        self.sd, self.hv, self.hd, self.ht, self.ac = sd, vis_heads, dec_heads, txt_heads, autocast_dtype
+
+    def _run(self, fn):
+        if self.ac is None:
+            return fn()
+        with torch.autocast("cpu", dtype=self.ac):
+            out = fn()
+        f32 = lambda t: t.float() if torch.is_tensor(t) else type(t)(f32(u) for u in t)
+        return f32(out)
 
     def get_clip_text_feature(self, text, normalize=True):
-        return O.clip_text_feature(self.sd, text, self.ht, normalize)
+        return self._run(lambda: O.clip_text_feature(self.sd, text, self.ht, normalize))
 
     def get_clip_image_feature(self, image, normalize=True):
-        return O.clip_image_feature(self.sd, image, self.hv, normalize)
+        return self._run(lambda: O.clip_image_feature(self.sd, image, self.hv, normalize))
 
     def get_reconstruction_latents(self, image):
-        return O.reconstruction_latents(self.sd, image, self.hv)
+        return self._run(lambda: O.reconstruction_latents(self.sd, image, self.hv))
 
     def get_latents_decoded_images(self, latents):
-        return O.decoder_forward(self.sd, latents.float(), self.hd)
+        return self._run(lambda: O.decoder_forward(self.sd, latents.float(), self.hd))
 
     def get_intermediate_layers_feature(self, image, n=1, reshape=False, return_class_token=False, norm=True):
-        return O.intermediate_layers(self.sd, image, self.hv, n=n, reshape=reshape, return_class_token=return_class_token, norm=norm)
+        return self._run(lambda: O.intermediate_layers(self.sd, image, self.hv, n=n, reshape=reshape,
+                                                       return_class_token=return_class_token, norm=norm))
 
 
 def run_all(model, device, images: torch.Tensor, targets: torch.Tensor, vocab: int, ctx: int, seed: int = 0) -> Dict[str, torch.Tensor]:

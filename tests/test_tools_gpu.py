@@ -32,8 +32,9 @@ def test_eval_tools_plumbing_on_the_hip_model(golden_sd):
     model.load_state_dict(golden_sd, strict=True)
     model = model.to(DEV).eval()
     ours = T.run_all(model, torch.device(DEV), images, targets, V, C)
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        noisy = T.run_all(T.OracleModel(golden_sd, 2, 2, 2), torch.device("cpu"), images, targets, V, C)
+    # E_ref: the MODEL calls of the oracle under bf16 autocast, the tools' own arithmetic (probe training, metrics) in fp32 -- the
+    # reference tools wrap only the model call in their autocast context
+    noisy = T.run_all(T.OracleModel(golden_sd, 2, 2, 2, autocast_dtype=torch.bfloat16), torch.device("cpu"), images, targets, V, C)
     for k in ("zs.classifier", "zs.logits", "rec.latents", "rec.recon_denorm", "lp.patch0", "lp.cls0", "lp.patch1", "lp.cls1",
               "lp.input_1_avg", "lp.input_2", "lp.w_after"):
         ref = tg["out." + k]
