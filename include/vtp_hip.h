@@ -40,11 +40,13 @@ const char* vtp_last_error(void);
  *   VTP_EPI_F32         C f32  = resid + gamma * (acc + bias)            (bias/gamma/resid optional; block.py:293-294)
  *   VTP_EPI_SWIGLU      B rows interleaved [8 x w1 | 8 x w2] per 16; C bf16 [M, N/2] = silu(x1) * x2, C2 bf16 [M,N] = (x1|x2)
  *   VTP_EPI_GELU        C bf16 = gelu_erf(acc + bias), C2 bf16 = acc + bias (optional)
+ *   VTP_EPI_QUICK_GELU  the same with QuickGELU x * sigmoid(1.702 x) (text_quick_gelu; layers/activation.py:5-12)
  *   VTP_EPI_F32_ATOMIC  C f32 += alpha * acc, split-K over `splits` slices with fp32 atomics
  *   VTP_EPI_F32_SLAB    split-K slice z writes alpha * acc to C + z * (4*ldc2) floats with plain stores (wgrad; sum the
  *                       slabs with vtp_reduce_slabs).  The slice count actually used is vtp_gemm_splits(K, splits).
  */
-enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4, VTP_EPI_F32_SLAB = 5 };
+enum { VTP_EPI_BF16 = 0, VTP_EPI_F32 = 1, VTP_EPI_SWIGLU = 2, VTP_EPI_GELU = 3, VTP_EPI_F32_ATOMIC = 4, VTP_EPI_F32_SLAB = 5,
+       VTP_EPI_QUICK_GELU = 8 };
 int vtp_gemm_splits(int K, int splits);
 /* split-K factor the weight-gradient GEMM C[M,N] = A[K,M]^T B[K,N] should be launched with (tile configuration aware:
  * 256x256 8-phase kernel -> tiles x splits = one round of the CUs; ring kernel -> just under 512 workgroups) */
@@ -198,6 +200,8 @@ int vtp_gemm_dgrad_swiglu(const void* A, int lda, const void* WT, int ldb, const
                           int K, void* stream);
 /* GELU backward (text MLP, block.py:399): dx = dy * gelu'(pre). */
 int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream);
+/* dx = dy * QuickGELU'(pre)  (x sigmoid(1.702 x), layers/activation.py:5-12); bf16, n % 8 == 0 */
+int vtp_quick_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream);
 
 /* PixelShuffle(16) (pixel_decoder.py:160): t bf16 [B*h*w, 768] token-major -> img f32 [B,3,16h,16w]. */
 int vtp_pixel_shuffle16(const void* t, float* img, int B, int h, int w, void* stream);

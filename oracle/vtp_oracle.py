@@ -122,7 +122,10 @@ def self_attention(x: Tensor, sd: Dict[str, Tensor], pre: str, num_heads: int,
 
 
 def swiglu_ffn(x: Tensor, sd: Dict[str, Tensor], pre: str, lin=_plain_linear) -> Tensor:
-    """SwiGLUFFN.forward -- ffn.py:77-81."""
+    """SwiGLUFFN.forward -- ffn.py:77-81; with ffn_layer = "mlp" the block holds Mlp (fc1 -> nn.GELU -> fc2, ffn.py:21-48; dropout 0)."""
+    if pre + "fc1.weight" in sd:
+        h = F.gelu(lin(x, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"], pre + "fc1"))
+        return lin(h, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"], pre + "fc2")
     x1 = lin(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"], pre + "w1")
     x2 = lin(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"], pre + "w2")
     return lin(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"], pre + "w3")
@@ -251,7 +254,7 @@ def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre:
 # --------------------------------------------------------------------------------------------
 # CLIP text tower + heads -- vtp/models/encoders/text_transformer.py, modeling_vtp.py:244-333
 # --------------------------------------------------------------------------------------------
-def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True) -> Tensor:
+def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True, quick_gelu: bool = False) -> Tensor:
     """ResidualAttentionBlock.forward -- block.py:416-427 with nn.MultiheadAttention (packed
     in_proj, additive causal mask text_transformer.py:334-338) and exact-erf GELU MLP."""
     B, T, C = x.shape
@@ -261,19 +264,22 @@ def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True) -> 
     q, k, v = [t.transpose(1, 2) for t in (q, k, v)]
     o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
     o = o.transpose(1, 2).reshape(B, T, C)
-    x = x + F.linear(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
+    a = F.linear(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
+    x = x + (a * sd[pre + "ls_1.gamma"] if pre + "ls_1.gamma" in sd else a)  # LayerScale when ls_init_value is set (block.py:388,425)
     h = layernorm(x, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], 1e-5)
-    h = F.gelu(F.linear(h, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"]))
-    return x + F.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+    h = F.linear(h, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"])
+    h = h * torch.sigmoid(1.702 * h) if quick_gelu else F.gelu(h)  # QuickGELU (layers/activation.py:5-12) | nn.GELU
+    m = F.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+    return x + (m * sd[pre + "ls_2.gamma"] if pre + "ls_2.gamma" in sd else m)
 
 
 def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True, pool_type: str = "argmax",
-                      causal: bool = True) -> Tensor:
+                      causal: bool = True, quick_gelu: bool = False) -> Tensor:
     """VTPModel.get_clip_text_feature -- modeling_vtp.py:278-310; text_global_pool text_transformer.py:213-228 (argmax = EOT | first
     | last); causal = not text_no_causal_mask (text_transformer.py:285-288)."""
     x = F.embedding(text, sd["token_embedding.weight"]) + sd["positional_embedding"]
     for i in range(_depth(sd, "text_transformer.resblocks.")):
-        x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads, causal=causal)
+        x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads, causal=causal, quick_gelu=quick_gelu)
     x = layernorm(x, sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)
     if pool_type == "first":
         x = x[:, 0]

@@ -255,18 +255,49 @@ def test_clip_image_feature_variants_match_reference(clip_feat, ae_only):
         torch.testing.assert_close(lo, li, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("pool,no_causal", [("first", False), ("last", False), ("argmax", True), ("last", True)])
-def test_text_pooling_and_mask_variants_match_reference(pool, no_causal):
-    """text_global_pool first / last and no_causal_mask (text_transformer.py:213-228,285-288) -- the oracle branch behind the
-    round-4 text-tower variants, against the real class"""
+@pytest.mark.parametrize("pool,no_causal,ls,quick", [("first", False, None, False), ("last", False, None, False), ("argmax", True, None, False),
+                                                      ("last", True, None, False), ("argmax", False, 0.1, False), ("argmax", False, None, True)])
+def test_text_pooling_and_mask_variants_match_reference(pool, no_causal, ls, quick):
+    """text_global_pool first / last, no_causal_mask, LayerScale and QuickGELU (text_transformer.py:213-228,285-288; block.py:388,399,
+    425-426; layers/activation.py:5-12) --
+    the oracle branches behind the round-4 text-tower variants, against the real class (state_dict keys / shapes of ours too)"""
     from oracle.ref_stubs import TINY, load_reference
+    from vtp_amd import VTPConfig, VTPModel
     ref = load_reference()
     torch.manual_seed(5)
-    m = ref.VTPModel(ref.VTPConfig(**dict(TINY, text_pool_type=pool, text_no_causal_mask=no_causal))).eval()
+    kw = dict(TINY, text_pool_type=pool, text_no_causal_mask=no_causal, text_ls_init_value=ls, text_quick_gelu=quick)
+    m = ref.VTPModel(ref.VTPConfig(**kw)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".gamma"):  # LayerScale gammas are torch.empty until reset_parameters: give them values
+                p.copy_(0.5 + torch.rand_like(p))
     sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in VTPModel(VTPConfig(**kw)).state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
     text = torch.randint(1, 500, (3, 16))
     text[:, 9] = 511
     with torch.no_grad():
         want = m.get_clip_text_feature(text)
-        got = O.clip_text_feature(sd, text, 2, pool_type=pool, causal=not no_causal)
+        got = O.clip_text_feature(sd, text, 2, pool_type=pool, causal=not no_causal, quick_gelu=quick)
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("vis,dec", [("mlp", "mlp"), ("swiglu64", "swiglu")])
+def test_ffn_layer_variants_match_reference(vis, dec):
+    """ffn_layer = "mlp" (GELU Mlp, ffn.py:21-48) and the aligned SwiGLU widths (vision_transformer.py:22-28): parameter names /
+    shapes of vtp_amd.VTPModel against the real class, and the oracle's FFN branch against its encode -> decode"""
+    from vtp_amd import VTPConfig, VTPModel
+    ref = load_reference()
+    kw = dict(TINY, vision_ffn_layer=vis, decoder_ffn_layer=dec)
+    torch.manual_seed(9)
+    m = ref.VTPModel(ref.VTPConfig(**kw)).eval()
+    sd = m.state_dict()
+    ours = VTPModel(VTPConfig(**kw)).state_dict()
+    assert {k: tuple(v.shape) for k, v in ours.items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    img = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        lat_ref = m.get_reconstruction_latents(img)
+        rec_ref = m.get_latents_decoded_images(lat_ref)
+        lat = O.reconstruction_latents(sd, img, 2)
+        rec = O.decoder_forward(sd, lat, 2)
+    torch.testing.assert_close(lat, lat_ref, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(rec, rec_ref, rtol=2e-4, atol=2e-5)

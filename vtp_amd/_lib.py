@@ -29,6 +29,7 @@ SIGNATURES = {
     "vtp_swiglu_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "vtp_gemm_dgrad_swiglu": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "vtp_gelu_bwd": [_P, _P, _P, _L, _P],
+    "vtp_quick_gelu_bwd": [_P, _P, _P, _L, _P],
     "vtp_pixel_shuffle16": [_P, _P, _I, _I, _I, _P],
     "vtp_pixel_unshuffle16": [_P, _P, _I, _I, _I, _P],
     "vtp_l1_loss_fwd_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P],

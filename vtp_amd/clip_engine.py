@@ -25,6 +25,7 @@ class TextEngine:
         # text_transformer.py:285-288: no_causal_mask drops the additive causal mask (full attention over the T tokens);
         # text_global_pool (:213-228): the pooled row is the first / last token or the arg-max id (EOT) of every caption
         self.stack.causal = not cfg.text_no_causal_mask
+        self.stack.quick_gelu = bool(cfg.text_quick_gelu)  # act_layer = QuickGELU (modeling_vtp.py:139)
         self.pool = cfg.text_pool_type
         # text_projection is stored [width, output_dim] and applied as x @ P (modeling_vtp.py:308): as a Lin with
         # N = width, K = output_dim its bf16 copy `w` is P and `wT` is P^T (the K-contiguous operand of the forward GEMM)

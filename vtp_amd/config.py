@@ -72,7 +72,8 @@ class VTPConfig:
         for pre in ("vision", "decoder", "text"):
             d, h = getattr(self, f"{pre}_embed_dim"), getattr(self, f"{pre}_num_heads")
             need(d % h == 0 and d // h == 64, f"{pre}: head_dim must be 64 (got {d}/{h})")
-        need(self.vision_ffn_layer == "swiglu" and self.decoder_ffn_layer == "swiglu", "only the swiglu FFN is implemented")
+        for pre in ("vision", "decoder"):  # ffn_layer_dict, vision_transformer.py:22-28
+            need(getattr(self, f"{pre}_ffn_layer") in FFN_LAYERS, f"{pre}_ffn_layer must be one of {sorted(FFN_LAYERS)}")
         need(self.vision_norm_layer in ("rmsnorm", "layernorm"), "vision_norm_layer must be rmsnorm|layernorm")
         need(self.decoder_norm_layer in ("rmsnorm", "layernorm"), "decoder_norm_layer must be rmsnorm|layernorm")
         need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
@@ -80,8 +81,6 @@ class VTPConfig:
         need(self.text_pool_type in ("argmax", "first", "last"),
              "text_pool_type must be argmax | first | last ('none' returns per-token features: not implemented)")
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
-        need(not self.text_quick_gelu, "quick_gelu is not implemented")
-        need(self.text_ls_init_value is None, "LayerScale in the text tower (text_ls_init_value) is not implemented")
 
     def to_dict(self):
         d = {k: v for k, v in self.__dict__.items() if k != "extra"}
@@ -144,6 +143,16 @@ class VTPConfig:
             elif arg not in cls._YAML_OPTIONAL:
                 raise KeyError(f"{yaml_path}: missing {sec}.{key}")
         return cls(**kw)
+
+
+# ffn_layer_dict (vision_transformer.py:22-28): name -> alignment of the SwiGLU hidden width (None: the plain GELU Mlp, ffn.py:21-48)
+FFN_LAYERS = {"mlp": None, "swiglu": 8, "swiglu32": 32, "swiglu64": 64, "swiglu128": 128}
+
+
+def ffn_hidden(dim: int, ratio: float, ffn_layer: str) -> int:
+    """hidden width of a block's FFN: Mlp int(dim * ratio) (block.py:176); SwiGLUFFN 2/3 of that, aligned (ffn.py:71-72)"""
+    align = FFN_LAYERS[ffn_layer]
+    return int(dim * ratio) if align is None else swiglu_hidden(dim, ratio, align)
 
 
 def swiglu_hidden(dim: int, ratio: float = 4.0, align_to: int = 8) -> int:

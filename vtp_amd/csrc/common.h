@@ -100,6 +100,13 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// QuickGELU (layers/activation.py:5-12): x * sigmoid(1.702 x), and its derivative s (1 + 1.702 x (1 - s))
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_f(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+  const float s = sigmoid_f(1.702f * x);
+  return s * (1.f + 1.702f * x * (1.f - s));
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace vtp

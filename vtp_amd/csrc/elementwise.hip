@@ -427,13 +427,14 @@ __global__ __launch_bounds__(256) void swiglu_bwd_rows_kernel(const bf16* __rest
   }
 }
 
+template <bool QUICK>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre,
                                                        bf16* __restrict__ dx, long n) {
   const long n8 = n / 8;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256L) {
     bf16x8 g = *(const bf16x8*)(dy + 8 * i), p = *(const bf16x8*)(pre + 8 * i), o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(g[e]) * gelu_erf_grad(bf2f(p[e])));
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(g[e]) * (QUICK ? quick_gelu_grad(bf2f(p[e])) : gelu_erf_grad(bf2f(p[e]))));
     *(bf16x8*)(dx + 8 * i) = o;
   }
 }
@@ -651,8 +652,14 @@ extern "C" int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float
 
 extern "C" int vtp_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream) {
   VTP_REQUIRE(dy && pre && dx && n > 0 && n % 8 == 0, "vtp_gelu_bwd: bad argument (n %% 8 == 0)");
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n);
+  hipLaunchKernelGGL(gelu_bwd_kernel<false>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n);
   return check_launch("gelu_bwd");
+}
+
+extern "C" int vtp_quick_gelu_bwd(const void* dy, const void* pre, void* dx, long n, void* stream) {
+  VTP_REQUIRE(dy && pre && dx && n > 0 && n % 8 == 0, "vtp_quick_gelu_bwd: bad argument (n %% 8 == 0)");
+  hipLaunchKernelGGL(gelu_bwd_kernel<true>, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n);
+  return check_launch("quick_gelu_bwd");
 }
 
 extern "C" int vtp_pixel_shuffle16(const void* t, float* img, int B, int h, int w, void* stream) {

@@ -571,6 +571,8 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
                            int a_grp, int a_pre, int c_grp, int c_pre, int splits, float alpha, void* stream) {
   VTP_REQUIRE(A && B && C, "vtp_gemm_nt: null operand");
   VTP_REQUIRE(M > 0 && N > 0 && K > 0, "vtp_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+  const int act_quick = epilogue == VTP_EPI_QUICK_GELU;  // the GELU epilogue with the other activation: same kernels, same dispatch
+  if (act_quick) epilogue = VTP_EPI_GELU;
   VTP_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "vtp_gemm_nt: K, lda, ldb must be multiples of 8 (16-B rows)");
   VTP_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "vtp_gemm_nt: N and ldc must be multiples of 4");
   VTP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "vtp_gemm_nt: operands must be 16-B aligned");
@@ -583,6 +585,7 @@ extern "C" int vtp_gemm_nt(const void* A, int lda, const void* B, int ldb, void*
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldc2 = ldc2;
   a.a_grp = a_grp; a.a_pre = a_pre; a.c_grp = c_grp; a.c_pre = c_pre; a.alpha = alpha;
   a.b_grp = 0; a.b_pre = 0;
+  a.act_quick = act_quick;
   a.xcd_swizzle = swz_flags();
   int ks = ((K + splits - 1) / splits + 63) / 64 * 64;
   a.k_split = ks;

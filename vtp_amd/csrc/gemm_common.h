@@ -44,6 +44,7 @@ struct GemmArgs {
   // null: plain epilogue.
   const bf16* swiglu_pre;
   int swiglu_ld;
+  int act_quick;  // EPI_GELU only: 1 = QuickGELU x sigmoid(1.702 x) (text_quick_gelu, layers/activation.py:5-12) instead of erf-GELU
   // in-launch split-K combine of the 256 x 256 kernel (few-tile shapes with a long K): fp32 partial sums [tiles][splits] x 256 KiB and
   // one arrival ticket per tile; null: off.  Set by the launcher (per-stream scratch), never by callers.
   float* part;
@@ -435,7 +436,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
               if (p.C2) *(bf16x4*)((bf16*)p.C2 + (size_t)mc * p.ldc2 + n) = pre;
               f32x4 g;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) g[e] = gelu_erf(bf2f(pre[e]));
+              for (int e = 0; e < 4; ++e) g[e] = p.act_quick ? quick_gelu_f(bf2f(pre[e])) : gelu_erf(bf2f(pre[e]));
               *(bf16x4*)((bf16*)p.C + (size_t)mc * p.ldc + n) = __builtin_convertvector(g, bf16x4);
             } else {  // EPI_F32: out = resid + gamma * (acc + bias)
               if (p.gamma) {

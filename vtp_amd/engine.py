@@ -366,9 +366,9 @@ class BlockW:
 # ResidualAttentionBlock + nn.MultiheadAttention)
 _NAMES = {
     "vit": dict(n1="norm1", n2="norm2", qkv_w="attn.qkv.weight", qkv_b="attn.qkv.bias", proj_w="attn.proj.weight",
-                proj_b="attn.proj.bias"),
+                proj_b="attn.proj.bias", ls1="ls1.gamma", ls2="ls2.gamma"),
     "text": dict(n1="ln_1", n2="ln_2", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias",
-                 proj_w="attn.out_proj.weight", proj_b="attn.out_proj.bias"),
+                 proj_w="attn.out_proj.weight", proj_b="attn.out_proj.bias", ls1="ls_1.gamma", ls2="ls_2.gamma"),
 }
 
 
@@ -377,8 +377,12 @@ class Stack:
     style "text": CLIP ResidualAttentionBlock (causal attention, no RoPE, LayerNorm eps 1e-5, erf-GELU MLP of width H)."""
 
     def __init__(self, store: ParamStore, prefix: str, depth: int, D: int, heads: int, H: int, norm: str,
-                 style: str = "vit"):
+                 style: str = "vit", ffn: str = "swiglu"):
         self.store, self.depth, self.D, self.heads, self.H, self.style = store, depth, D, heads, H, style
+        # FFN of the blocks: SwiGLUFFN (w1 | w2 fused + w3) or the erf-GELU MLP -- `mlp.fc1 / fc2` in ViT blocks with ffn_layer = "mlp"
+        # (ffn.py:21-48), `mlp.c_fc / c_proj` in the text tower
+        self.swiglu = style == "vit" and ffn != "mlp"
+        self.quick_gelu = False  # GELU MLPs: QuickGELU instead of erf-GELU (text_quick_gelu; set by the owner)
         self.kind = ops.NORM_RMS if norm == "rmsnorm" else ops.NORM_LN
         if style == "text":
             self.eps = 1e-5  # nn.LayerNorm default (normalization.py:25-31)
@@ -399,16 +403,17 @@ class Stack:
                 b.n1b = b.gn1b = b.n2b = b.gn2b = None
             b.qkv = store.lin(pre + nm["qkv_w"], pre + nm["qkv_b"], 3 * D, D)
             b.proj = store.lin(pre + nm["proj_w"], pre + nm["proj_b"], D, D)
-            if style == "vit":
+            if self.swiglu:
                 b.w12 = store.swiglu(pre + "mlp.", H, D)
                 b.w3 = store.lin(pre + "mlp.w3.weight", pre + "mlp.w3.bias", D, H)
             else:
-                b.fc = store.lin(pre + "mlp.c_fc.weight", pre + "mlp.c_fc.bias", H, D)
-                b.w3 = store.lin(pre + "mlp.c_proj.weight", pre + "mlp.c_proj.bias", D, H)
-            b.ls1 = store.p(pre + "ls1.gamma") if store.has(pre + "ls1.gamma") else None
-            b.ls2 = store.p(pre + "ls2.gamma") if store.has(pre + "ls2.gamma") else None
-            b.gls1 = store.g(pre + "ls1.gamma") if b.ls1 is not None else None
-            b.gls2 = store.g(pre + "ls2.gamma") if b.ls2 is not None else None
+                n1, n2 = ("fc1", "fc2") if style == "vit" else ("c_fc", "c_proj")
+                b.fc = store.lin(f"{pre}mlp.{n1}.weight", f"{pre}mlp.{n1}.bias", H, D)
+                b.w3 = store.lin(f"{pre}mlp.{n2}.weight", f"{pre}mlp.{n2}.bias", D, H)
+            b.ls1 = store.p(pre + nm["ls1"]) if store.has(pre + nm["ls1"]) else None  # LayerScale (misc.py:7-26; text: block.py:388,399)
+            b.ls2 = store.p(pre + nm["ls2"]) if store.has(pre + nm["ls2"]) else None
+            b.gls1 = store.g(pre + nm["ls1"]) if b.ls1 is not None else None
+            b.gls2 = store.g(pre + nm["ls2"]) if b.ls2 is not None else None
             # QK normalisation (attention.py:67-68): RMSNorm(head_dim) weights of q and k, shared by the heads
             qn = pre + "attn.q_norm.weight"
             if store.has(qn):
@@ -496,6 +501,8 @@ class Stack:
         buffer of a given size is allocated ONCE and kept for the lifetime of the stack: captured hipGraph segments bake its
         address, so it is only ever refreshed in place -- switching the plan off, or alternating between plans of different sizes
         (steps with / without SSL crops), never frees or moves a buffer a graph may still read."""
+        if plan is not None and not self.swiglu:
+            raise NotImplementedError("stochastic depth is implemented for SwiGLU ViT blocks only (not the GELU-Mlp FFN / the text tower)")
         if plan is None:
             if self.drop_plan is not None:
                 self.last_drop_plan = self.drop_plan  # introspection (tests replay the subsets of the step that just ran)
@@ -666,7 +673,7 @@ class Stack:
         segs = [(B, N, rope)] if segs is None else segs
         M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
-        vit = self.style == "vit"
+        vit = self.swiglu  # (FFN kind; RoPE / naming follow self.style)
         fp8 = getattr(self, "fp8", None)
         if fp8 is not None and fp8["ready"] and not train:
             return self.forward_fp8(ws, x, segs, prefix_tokens, M)
@@ -709,7 +716,8 @@ class Stack:
             if vit:
                 ops.gemm_nt(xn2, b.w12.w12, hid, M=M, N=2 * H, K=D, c2=pre, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
             else:
-                ops.gemm_nt(xn2, b.fc.w, hid, M=M, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias, epi=EPI_GELU)
+                ops.gemm_nt(xn2, b.fc.w, hid, M=M, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias,
+                            epi=ops.EPI_QUICK_GELU if self.quick_gelu else EPI_GELU)
             ops.gemm_nt(hid, b.w3.w, xout, M=M, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, resid=xmid, epi=EPI_F32)
             if calib is not None:  # fp8 calibration pass: amax of the four GEMM inputs of this block
                 for j, tns in enumerate((xn1, o, xn2, hid)):
@@ -723,7 +731,7 @@ class Stack:
     # ---- fp8 (e4m3) inference forward: BASELINE config 5 (per-tensor scales: weights from their own amax, activations from a
     # calibration pass of the bf16 path over representative images)
     def fp8_begin_calibration(self):
-        if self.style != "vit" or self.D % 16 or self.H % 16 or self.qk_norm or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
+        if not self.swiglu or self.D % 16 or self.H % 16 or self.qk_norm or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
             raise NotImplementedError("fp8 forward: ViT blocks with D, H multiples of 16, no LayerScale, no QK normalisation")
         dev = self.store.device
         self.fp8 = {"ready": False, "amax": torch.zeros(self.depth, 4, dtype=F32, device=dev)}
@@ -799,7 +807,7 @@ class Stack:
         segs = [(B, N, rope)] if segs is None else segs
         M = sum(b * n for b, n, _ in segs)
         scale = 1.0 / math.sqrt(64.0)
-        vit = self.style == "vit"
+        vit = self.swiglu  # (FFN kind)
         # grouped weight gradients: the four dW of block i are ONE launch (split-K combine and bias-gradient column sums inside
         # it), issued at the start of block i - 1's backward so that it overlaps that block's dgrad / attention kernels; the dy
         # operands it reads (dpre, dmid_b, dqkv; dy_b already alternates) are therefore double-buffered by block parity
@@ -848,7 +856,7 @@ class Stack:
                 linear_bwd(ws, "w12", None, dpre, xn2, M, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T,
                            swiglu_h=H, defer=probs)
             else:
-                ops.gelu_bwd(dh, pre, dpre, M * H)
+                ops.gelu_bwd(dh, pre, dpre, M * H, quick=self.quick_gelu)
                 linear_bwd(ws, "fc", b.fc, dpre, xn2, M, dxn, defer=probs)
             # the norm backward kernels also sum the columns of their bf16 output = the bias gradient of the linear layer that
             # takes it as dy (proj here; the previous block's w3 below)
@@ -923,16 +931,17 @@ def rope_tables(periods: torch.Tensor, H: int, W: int, device) -> Tuple[torch.Te
 # =====================================================================================================================
 class TrunkEngine:
     def __init__(self, store: ParamStore, cfg, periods: torch.Tensor, prefix: str = "trunk."):
-        from .config import swiglu_hidden
+        from .config import ffn_hidden
         self.store = store
         self.prefix = prefix  # "trunk." (student) or "teacher_trunk." (EMA teacher, vtp.py:253-268)
         self.D, self.heads, self.depth = cfg.vision_embed_dim, cfg.vision_num_heads, cfg.vision_depth
-        self.H = swiglu_hidden(self.D, cfg.vision_mlp_ratio)
+        self.H = ffn_hidden(self.D, cfg.vision_mlp_ratio, cfg.vision_ffn_layer)
         self.kind = ops.NORM_RMS if cfg.vision_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
         self.periods = periods.detach().to("cpu")  # host copy: rope_tables must not touch the device during graph capture
         self.pe = store.lin(self.prefix + "patch_embed.proj.weight", self.prefix + "patch_embed.proj.bias", self.D, 768)  # W^T: the input-image gradient
-        self.stack = Stack(store, self.prefix + "blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer)
+        self.stack = Stack(store, self.prefix + "blocks.", self.depth, self.D, self.heads, self.H, cfg.vision_norm_layer,
+                           ffn=cfg.vision_ffn_layer)
         self.bott_dim = cfg.vision_feature_bottleneck
         self.bott = store.lin(self.prefix + "feature_bottleneck.weight", None, self.bott_dim, self.D) \
             if store.has(self.prefix + "feature_bottleneck.weight") else None
@@ -1070,16 +1079,17 @@ class TrunkCtx:
 # =====================================================================================================================
 class DecoderEngine:
     def __init__(self, store: ParamStore, cfg, periods: torch.Tensor):
-        from .config import swiglu_hidden
+        from .config import ffn_hidden
         self.store = store
         self.D, self.heads, self.depth = cfg.decoder_embed_dim, cfg.decoder_num_heads, cfg.decoder_depth
-        self.H = swiglu_hidden(self.D, 4.0)
+        self.H = ffn_hidden(self.D, 4.0, cfg.decoder_ffn_layer)
         self.kind = ops.NORM_RMS if cfg.decoder_norm_layer == "rmsnorm" else ops.NORM_LN
         self.eps = 1e-5 if self.kind == ops.NORM_RMS else 1e-6
         self.periods = periods.detach().to("cpu")
         self.cin = cfg.vision_feature_bottleneck
         self.pin = store.lin("pixel_decoder.proj_in.weight", "pixel_decoder.proj_in.bias", self.D, self.cin)
-        self.stack = Stack(store, "pixel_decoder.blocks.", self.depth, self.D, self.heads, self.H, cfg.decoder_norm_layer)
+        self.stack = Stack(store, "pixel_decoder.blocks.", self.depth, self.D, self.heads, self.H, cfg.decoder_norm_layer,
+                           ffn=cfg.decoder_ffn_layer)
         self.pout = store.lin("pixel_decoder.proj_out.weight", "pixel_decoder.proj_out.bias", 768, self.D)
         self.ws: Dict[tuple, Workspace] = {}
 

@@ -16,7 +16,7 @@ from torch import nn
 
 from . import autograd as ag
 from . import ops
-from .config import VTPConfig, swiglu_hidden
+from .config import VTPConfig, ffn_hidden, swiglu_hidden
 from .engine import BF, F32, DecoderEngine, ParamStore, TrunkEngine
 
 
@@ -44,9 +44,10 @@ def _norm(dim: int, bias: bool) -> nn.Module:
     return m
 
 
-def _vit_block(D: int, H: int, norm: str, init_values=None, qk_norm: bool = False) -> nn.Module:
+def _vit_block(D: int, H: int, norm: str, init_values=None, qk_norm: bool = False, ffn: str = "swiglu") -> nn.Module:
     """Parameter tree of SelfAttentionBlock (block.py:159-187); ls1 / ls2 = LayerScale gammas (misc.py:7-26) when `init_values`;
-    attn.q_norm / attn.k_norm = RMSNorm(head_dim = 64) weights when `qk_norm` (attention.py:67-68)."""
+    attn.q_norm / attn.k_norm = RMSNorm(head_dim = 64) weights when `qk_norm` (attention.py:67-68); mlp = SwiGLUFFN (w1, w2, w3) or
+    the GELU Mlp (fc1, fc2; ffn.py:21-48) when ffn == "mlp"."""
     b = _holder()
     b.norm1 = _norm(D, norm != "rmsnorm")
     b.attn = _holder()
@@ -61,9 +62,13 @@ def _vit_block(D: int, H: int, norm: str, init_values=None, qk_norm: bool = Fals
         b.ls1.init_values = float(init_values)
     b.norm2 = _norm(D, norm != "rmsnorm")
     b.mlp = _holder()
-    b.mlp.w1 = _linear(H, D)
-    b.mlp.w2 = _linear(H, D)
-    b.mlp.w3 = _linear(D, H)
+    if ffn == "mlp":
+        b.mlp.fc1 = _linear(H, D)
+        b.mlp.fc2 = _linear(D, H)
+    else:
+        b.mlp.w1 = _linear(H, D)
+        b.mlp.w2 = _linear(H, D)
+        b.mlp.w3 = _linear(D, H)
     if init_values:
         b.ls2 = _holder()
         b.ls2.gamma = _param(D)
@@ -95,8 +100,9 @@ class VTPModel(nn.Module):
         t.patch_embed.proj.bias = _param(D)
         t.rope_embed = _holder()
         t.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
-        Hv = swiglu_hidden(D, c.vision_mlp_ratio)
-        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer, c.vision_init_values, c.vision_use_qk_norm) for _ in range(c.vision_depth)])
+        Hv = ffn_hidden(D, c.vision_mlp_ratio, c.vision_ffn_layer)
+        t.blocks = nn.ModuleList([_vit_block(D, Hv, c.vision_norm_layer, c.vision_init_values, c.vision_use_qk_norm, c.vision_ffn_layer)
+                                  for _ in range(c.vision_depth)])
         t.norm = _norm(D, c.vision_norm_layer != "rmsnorm")
         if c.vision_feature_bottleneck is not None and c.vision_feature_bottleneck != D:
             t.feature_bottleneck = _holder()
@@ -116,8 +122,9 @@ class VTPModel(nn.Module):
             d.proj_in.bias = _param(Dd)
             d.rope_embed = _holder()
             d.rope_embed.register_buffer("periods", _rope_periods(), persistent=True)
-            Hd = swiglu_hidden(Dd, 4.0)
-            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer, c.decoder_init_values, c.decoder_use_qk_norm) for _ in range(c.decoder_depth)])
+            Hd = ffn_hidden(Dd, 4.0, c.decoder_ffn_layer)
+            d.blocks = nn.ModuleList([_vit_block(Dd, Hd, c.decoder_norm_layer, c.decoder_init_values, c.decoder_use_qk_norm, c.decoder_ffn_layer)
+                                      for _ in range(c.decoder_depth)])
             d.norm = _norm(Dd, c.decoder_norm_layer != "rmsnorm")
             d.proj_out = _holder()
             d.proj_out.weight = _param(768, Dd, 1, 1)
@@ -140,6 +147,12 @@ class VTPModel(nn.Module):
                 r.mlp = _holder()
                 r.mlp.c_fc = _linear(int(Dt * c.text_mlp_ratio), Dt)
                 r.mlp.c_proj = _linear(Dt, int(Dt * c.text_mlp_ratio))
+                if c.text_ls_init_value is not None:  # LayerScale on both residual branches (block.py:388,399)
+                    for nm_ in ("ls_1", "ls_2"):
+                        ls = _holder()
+                        ls.gamma = _param(Dt)
+                        ls.init_values = float(c.text_ls_init_value)
+                        setattr(r, nm_, ls)
                 blocks.append(r)
             tt.resblocks = nn.ModuleList(blocks)
             self.text_transformer = tt
@@ -207,6 +220,9 @@ class VTPModel(nn.Module):
                 for ln in (r.ln_1, r.ln_2):
                     ln.weight.fill_(1.0)
                     ln.bias.zero_()
+                if c.text_ls_init_value is not None:
+                    r.ls_1.gamma.fill_(c.text_ls_init_value)
+                    r.ls_2.gamma.fill_(c.text_ls_init_value)
             self.ln_final.weight.fill_(1.0)
             self.ln_final.bias.zero_()
             nn.init.normal_(self.text_projection, std=W ** -0.5)

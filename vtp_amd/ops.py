@@ -7,6 +7,7 @@ import torch
 from . import _lib
 
 EPI_BF16, EPI_F32, EPI_SWIGLU, EPI_GELU, EPI_F32_ATOMIC, EPI_F32_SLAB = 0, 1, 2, 3, 4, 5
+EPI_QUICK_GELU = 8  # the GELU epilogue with x * sigmoid(1.702 x)
 NORM_RMS, NORM_LN = 0, 1
 
 
@@ -116,8 +117,11 @@ def swiglu_bwd(dh, x12, dx12, M, H, db12=None):
     _lib.check(_lib_().vtp_swiglu_bwd(_p(dh), _p(x12), _p(dx12), _p(db12), M, H, _s()), "vtp_swiglu_bwd")
 
 
-def gelu_bwd(dy, pre, dx, n):
-    _lib.check(_lib_().vtp_gelu_bwd(_p(dy), _p(pre), _p(dx), n, _s()), "vtp_gelu_bwd")
+def gelu_bwd(dy, pre, dx, n, quick: bool = False):
+    if quick:
+        _lib.check(_lib_().vtp_quick_gelu_bwd(_p(dy), _p(pre), _p(dx), n, _s()), "vtp_quick_gelu_bwd")
+    else:
+        _lib.check(_lib_().vtp_gelu_bwd(_p(dy), _p(pre), _p(dx), n, _s()), "vtp_gelu_bwd")
 
 
 def pixel_shuffle16(t, img, B, h, w):
