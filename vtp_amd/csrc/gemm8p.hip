@@ -38,8 +38,9 @@ constexpr int P8_REGION = 4096;
 constexpr int P8_LDS = P8_RING + 8 * P8_REGION;
 }  // namespace
 
-__device__ __forceinline__ void p8_wait_vm_halftiles(int n) {  // at most n (0..3) half-tiles = 2 n DMA pieces outstanding
-  if (n >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+__device__ __forceinline__ void p8_wait_vm_halftiles(int n) {  // at most n (0..4) half-tiles = 2 n DMA pieces outstanding
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -360,6 +361,42 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         p.timing[(size_t)(gridDim.x + blockIdx.x) * 64 + kt] = wall_clock64();
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       Frags b1, b2, a1[2], a2[2];
+#ifdef VTP_P8_TWO_PHASE
+      // EXPERIMENT: two phases of 16 MFMAs per k-tile instead of four of 8 (half as many barrier intervals per k-tile).
+      // ---- phase A: B-first, A-first, B-second -> quadrants (cols 0..63, rows 0..63); issues A-second of the next k-tile
+      load_b(kb, b1);
+      load_a(kb + P8_SLOT, a1);
+      load_b(kb + 2 * P8_SLOT, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_h < H) issue(I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      p8_wait_vm_halftiles(s_h - 4 * ktg - 4);  // A-second of THIS k-tile (read in phase B)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // phase B overwrites the three slots read here
+      seg_barrier();
+      mma2(acc[0][0], acc[0][1], b1, a1[0], a1[1]);
+      mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
+      if constexpr (TRANS) {
+        if (do_csum) add_csum(a1, 0);
+      }
+      seg_barrier();
+      // ---- phase B: A-second -> quadrants (cols 0..63, rows 64..127); issues B-first, A-first, B-second of the k-tile after next
+      load_a(kb + 3 * P8_SLOT, a2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s_h < H) issue(I0{});
+      if (s_h < H) issue(I1{});
+      if (s_h < H) issue(I2{});
+      __builtin_amdgcn_sched_barrier(0);
+      p8_wait_vm_halftiles(s_h - 4 * ktg - 7);  // B-first, A-first, B-second of the NEXT k-tile (read in its phase A)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next phase A overwrites the slot read here
+      seg_barrier();
+      mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
+      mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
+      if constexpr (TRANS) {
+        if (do_csum) add_csum(a2, 2);
+      }
+      seg_barrier();
+    }
+#else
       // ---- phase 0: B-first + A-first -> quadrant (cols 0..31, rows 0..63)
       load_b(kb, b1);
       __builtin_amdgcn_sched_barrier(0);
@@ -400,6 +437,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
       seg_barrier();
     }
+#endif
     if (wr == 0) seg_barrier();  // re-align the groups: both run the epilogue together
     stamp(ti, 1);
     if constexpr (TRANS) {
