@@ -24,6 +24,9 @@ TEXT = [("t_qkv", 2304, 768, "bf16"), ("t_proj", 768, 768, "f32"), ("t_fc", 3072
         ("t_dgrad_fc", 768, 3072, "bf16"), ("t_dgrad_cproj", 3072, 768, "bf16")]
 
 
+ALT = int(os.environ.get("ALT_CFG", "9"))  # the tile configuration measured against the dispatch (9: gemm8h, 10: gemm4w)
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     lib = _lib.load()
@@ -35,7 +38,7 @@ def main():
         b = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
         bias = torch.randn(N, device=dev, generator=g)
         fns = {}
-        for name, cfg in (("auto", -1), ("8p", 8), ("8h", 9)):
+        for name, cfg in (("auto", -1), ("8p", 8), ("8h", ALT)):
             if kind in ("bf16", "gelu"):
                 c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
                 kw = dict(bias=bias, epi=ops.EPI_BF16 if kind == "bf16" else ops.EPI_GELU)
@@ -66,7 +69,7 @@ def main():
             fns[name] = run
         t = timeit(fns)
         fl = 2.0 * M * N * K
-        print(f"{tag:16s} M={M:5d} N={N:5d} K={K:5d}: auto {t['auto']:7.1f} us {fl / t['auto'] / 1e6:7.1f} TF/s | 8h {t['8h']:7.1f} us "
+        print(f"{tag:16s} M={M:5d} N={N:5d} K={K:5d}: auto {t['auto']:7.1f} us {fl / t['auto'] / 1e6:7.1f} TF/s | cfg{ALT} {t['8h']:7.1f} us "
               f"{fl / t['8h'] / 1e6:7.1f} TF/s  x{t['auto'] / t['8h']:.2f} | 8p {t['8p']:7.1f} us {fl / t['8p'] / 1e6:7.1f} TF/s", flush=True)
     lib.vtp_set_gemm_tuning(-1, 3)
 

@@ -24,7 +24,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     for f in _sources() + hdrs + [os.path.join(ROOT, "include", "vtp_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())

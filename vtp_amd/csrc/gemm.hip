@@ -362,9 +362,19 @@ bool gemm8p_fits(const GemmArgs& a, bool trans);
 bool gemm8p_combine_ready(hipStream_t s);
 // gemm8h.hip: 128x256 half-size variant, two workgroups per CU (cfg 9; NT, one K slice)
 int launch_gemm8h_nt(const GemmArgs& a, int epi, hipStream_t s);
+// gemm4w.hip: 256x256, one software-pipelined wave per SIMD (cfg 10; NT, one K slice, no A row remap)
+int launch_gemm4w_nt(const GemmArgs& a, int epi, hipStream_t s);
 
 template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
+  if (cfg == 10) {
+    if constexpr (!TRANS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_SWIGLU || EPI == EPI_GELU)) {
+      if (splits == 1 && a.N % 256 == 0 && a.K % 128 == 0 && a.a_grp == 0 && a.conv_cin == 0 && !a.timing &&
+          gemm8p_fits(a, false))
+        return launch_gemm4w_nt(a, EPI, s);
+    }
+    cfg = TRANS ? 5 : 8;
+  }
   if (cfg == 9) {
     if constexpr (!TRANS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_SWIGLU || EPI == EPI_GELU)) {
       if (splits == 1 && a.N % 256 == 0 && gemm8p_fits(a, false)) return launch_gemm8h_nt(a, EPI, s);
