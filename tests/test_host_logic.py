@@ -348,8 +348,9 @@ def test_bench_flop_accounting_matches_survey():
 
 def test_gemm_dispatch_table_of_the_step():
     """vtp_gemm_nt_config (host-only): the measured kernel choice for the GEMM shapes of the VTP-B step -- 8 = 256x256 8-phase
-    kernel, 9 = 128x256 half-size kernel with two workgroups per CU (round 4), 7 = 128x64 ring tiles, 5 / 0 = 128x128 ring; slices =
-    in-launch split-K.  Pinned because every row is a measurement (profiles/r03_gemm8p_bench.log, profiles/r04_gemm8h_bench.log,
+    kernel, 9 = 128x256 half-size kernel with two workgroups per CU (round 4), 10 = 256x256 one-wave-per-SIMD kernel with the
+    hand-scheduled k loop (round 4: plain bf16 epilogue, K >= 2048, >= 192 tiles), 7 = 128x64 ring tiles, 5 / 0 = 128x128 ring; slices =
+    in-launch split-K.  Pinned because every row is a measurement (profiles/r03_gemm8p_bench.log, profiles/r04_gemm8h_bench.log, profiles/r04_gemm4w_bench.log,
     tools/text_gemm_ab.py, tools/proto_gemm_ab.py) that an edit of the heuristics can silently undo."""
     from vtp_amd import _lib, ops
     lib = _lib.load()
@@ -357,7 +358,8 @@ def test_gemm_dispatch_table_of_the_step():
     want = {
         # list forward / backward of the trunk (34144 rows), teacher (16448), pixel decoder (8192)
         (34144, 2304, 768, BF): (8, 0), (34144, 768, 768, F32): (8, 0), (34144, 4096, 768, SW): (8, 0), (34144, 768, 2048, F32): (8, 0),
-        (34144, 768, 4096, BF): (8, 0), (34144, 2048, 768, BF): (8, 0), (16448, 768, 768, F32): (8, 0), (16448, 4096, 768, SW): (9, 0),
+        (34144, 768, 4096, BF): (10, 0), (34144, 768, 2304, BF): (10, 0), (16448, 768, 4096, BF): (10, 0), (34144, 768, 2048, BF): (10, 0),
+        (34144, 2048, 768, BF): (8, 0), (16448, 768, 768, F32): (8, 0), (16448, 4096, 768, SW): (9, 0),
         (8192, 2304, 768, BF): (8, 0), (8192, 4096, 768, SW): (8, 0), (8192, 768, 4096, BF): (8, 2),
         (8192, 768, 2048, F32): (7, 0), (8192, 768, 768, F32): (7, 0), (8192, 768, 2304, BF): (9, 0), (8192, 768, 768, BF): (9, 0),
         (2464, 3072, 768, BF): (9, 0),

@@ -492,9 +492,23 @@ static int pick_cfg(int M, int N, int K, int epilogue, int splits) {
   return 5;                                     // short K (768..2304): 8-wave 128x128 hides the DMA latency best
 }
 
-// the dispatch of the NT entry points: the measured table above, then the half-size kernel where it wins
+// the one-wave-per-SIMD kernel with the hand-scheduled k loop (cfg 10, gemm4w.hip): its k loop keeps the matrix pipe 85 % busy against 67 %
+// (profiles/r04_pmc_sq_cal_16384x4096x8192_cfg{8,10}.json; wall-time gain 11 .. 14 %: the chip answers the higher utilisation with a
+// ~10 % lower clock), but a tile's epilogue runs on ONE wave per SIMD and nothing overlaps it.  Measured per shape
+// (tools/gemm8h_bench.py with ALT_CFG=10, profiles/r04_gemm4w_bench.log): plain bf16 epilogue with K >= 2048 and at least ~3/4 of a
+// round of 256 x 256 tiles x1.05 .. 1.12 (the w12 / qkv dgrads at M = 34144 and 16448); K = 768 x0.97 .. 0.99; the fused epilogues
+// (RoPE x0.86, SwiGLU x0.94, SwiGLU backward x0.95, fp32 residual x0.88 .. 0.92) and few-tile shapes lose.
+static bool use_4w_nt(const GemmArgs& a, int epilogue) {
+  if (epilogue != VTP_EPI_BF16 || a.rope_pos || a.swiglu_pre || a.a_grp || a.conv_cin || a.timing) return false;
+  if (a.N % 256 != 0 || a.K % 128 != 0 || a.K < 2048) return false;
+  return cdiv(a.M, 256) * (a.N / 256) >= 192;
+}
+
+// the dispatch of the NT entry points: the measured table above, then the half-size / one-wave-per-SIMD kernels where they win
 static int pick_cfg_nt(const GemmArgs& a, int epilogue, int splits) {
   const int cfg = pick_cfg(a.M, a.N, a.K, epilogue, splits);
+  static const bool use_4w = [] { const char* e = getenv("VTP_GEMM4W"); return !(e && e[0] == '0'); }();  // VTP_GEMM4W=0: same-box A/B
+  if (use_4w && g_force_cfg < 0 && splits == 1 && use_4w_nt(a, epilogue) && gemm8p_fits(a, false)) return 10;
   static const bool use_8h = [] { const char* e = getenv("VTP_GEMM8H"); return !(e && e[0] == '0'); }();  // VTP_GEMM8H=0: same-box A/B of the step
   if (use_8h && g_force_cfg < 0 && splits == 1 && a.a_grp == 0 && use_8h_nt(a, epilogue) && gemm8p_fits(a, false)) return 9;
   return cfg;
