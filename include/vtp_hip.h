@@ -69,6 +69,9 @@ int vtp_gemm_tn(const void* A, int lda, const void* B, int ldb, void* C, int ldc
  * probs: device array of nprob records of 16 int64 {A, B, C, colsum | lda, ldb, ldc | M, N | c_grp, c_pre | tile0 | accumulate | 0 0 0};
  * part: ntiles * splits_eff * 65536 floats, ticket: ntiles ints, zero before the first launch (the kernel leaves them zero). */
 int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, void* stream);
+/* the same launch with the kernel named: 0 = the 8-phase kernel (= vtp_gemm_tn_grouped), 1 = the one-wave-per-SIMD kernel with the
+ * hand-scheduled k loop (needs K % 8 == 0; bit-identical results per K slice) */
+int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, int kernel, void* stream);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);

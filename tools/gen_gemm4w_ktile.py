@@ -92,6 +92,94 @@ def body(diag=0):
     return L
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# TN (weight gradient: C = A^T B, A [K, M], B [K, N], k along the rows of both operands).  Same X / Y schedule; what differs:
+#   * a staged k-tile = eight 8-KiB sub-images [64 k][64 columns] (128-B rows: A columns wr*128 + {0..63 | 64..127}, B likewise; the
+#     16-B chunk index of k-row r is XORed with 4 (r & 1)); wave w stages A sub-image w and B sub-image w: 8 pieces of 8 k-rows;
+#     the pieces' k-rows beyond the slice's K range read a zero block instead (per-piece scalar select)
+#   * a fragment = two ds_read_b64_tr_b16 (k rows +0 and +4) -> the fragment registers are PHYSICAL (v64..v255: an asm operand cannot
+#     name half of a register quadruple); the first fragments are read inside the asm
+#   * optional bias-gradient column sums: v_dot2_f32_bf16 of every A fragment against ones (cs0..3 = the wave's four row blocks)
+# Read addresses: a{E|O}{slot} / b{E|O}{slot} = the lane's address in 32-column block 0 / 1 of the wave's A / B sub-image 0 of the slot
+# (sub-image 1 = + 8192; k-step ks = + ks * 2048; second half = + 512).
+def FR(kind, idx):  # first register of fragment idx of set l | h | p | q
+    return {"l": 64, "h": 96, "p": 128, "q": 192}[kind] + 4 * idx
+
+
+def tn_frag_reads(kind, idx, addr, off):
+    r = FR(kind, idx)
+    return [f"ds_read_b64_tr_b16 v[{r}:{r + 1}], %[{addr}] offset:{off}", f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], %[{addr}] offset:{off + 512}"]
+
+
+def tn_piece(L, which, n, slot):
+    L += [f"s_cmp_gt_i32 %[kr{which}], 0", f"s_cselect_b64 %[sb], %[mat{which}], %[zb]", "s_cselect_b64 vcc, -1, 0",
+          f"v_cndmask_b32 %[vt], %[zoff], %[pe{which}], vcc", f"global_load_lds_dwordx4 %[vt], %[sb]",
+          f"v_add_u32 %[pe{which}], %[step{which}], %[pe{which}]", f"s_sub_u32 %[kr{which}], %[kr{which}], 8"]
+
+
+def tn_ktile(L, slot, bc, bn, csum, diag):
+    o = 1 - slot
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    # ---- X: rows 0..63 (A-lo x B); fetch A-hi of this k-tile; stage B of the k-tile after next
+    reads = []
+    for ks in range(4):
+        for b in range(2):
+            reads += tn_frag_reads("h", ks * 2 + b, f"a{'EO'[b]}{slot}", 8192 + ks * 2048)
+    dots = [(f"cs{j}", FR("l", ks * 2 + j) + w) for ks in range(4) for j in range(2) for w in range(4)]
+    for g in range(16):
+        ks, q = g >> 2, g & 3
+        j, i0 = q >> 1, (q & 1) * 2
+        if g in DMA_GROUPS and diag != 3:
+            L.append(f"s_mov_b32 m0, %[db{slot}]" if g == 0 else "s_add_u32 m0, m0, 0x400")
+        for i in (i0, i0 + 1):
+            rb, ra = FR(bc, ks * 4 + i), FR("l", ks * 2 + j)
+            L.append(f"v_mfma_f32_32x32x16_bf16 %[c{i}{j}], v[{rb}:{rb + 3}], v[{ra}:{ra + 3}], %[c{i}{j}]")
+            if i == i0:
+                L.append(reads[g])
+                if csum:
+                    for d, r in dots[2 * g:2 * g + 2]:
+                        L.append(f"v_dot2_f32_bf16 %[{d}], v{r}, %[ones], %[{d}]")
+        if g in DMA_GROUPS and diag != 3:
+            tn_piece(L, "b", DMA_GROUPS.index(g), slot)
+    L += ["s_waitcnt vmcnt(8) lgkmcnt(0)", "s_barrier"]
+    # ---- Y: rows 64..127 (A-hi x B); fetch A-lo + B of the next k-tile (other slot); stage A of the k-tile after next
+    reads = []
+    for ks in range(4):
+        for b in range(2):
+            reads += tn_frag_reads("l", ks * 2 + b, f"a{'EO'[b]}{o}", ks * 2048)
+        for i in range(4):
+            reads += tn_frag_reads(bn, ks * 4 + i, f"b{'EO'[i & 1]}{o}", (i >> 1) * 8192 + ks * 2048)
+    dots = [(f"cs{2 + j}", FR("h", ks * 2 + j) + w) for ks in range(4) for j in range(2) for w in range(4)]
+    for g in range(16):
+        ks, q = g >> 2, g & 3
+        j, i0 = q >> 1, (q & 1) * 2
+        if g in DMA_GROUPS and diag != 3:
+            L.append(f"s_mov_b32 m0, %[da{slot}]" if g == 0 else "s_add_u32 m0, m0, 0x400")
+        for i in (i0, i0 + 1):
+            rb, ra = FR(bc, ks * 4 + i), FR("h", ks * 2 + j)
+            L.append(f"v_mfma_f32_32x32x16_bf16 %[c{i}{2 + j}], v[{rb}:{rb + 3}], v[{ra}:{ra + 3}], %[c{i}{2 + j}]")
+            L += reads[3 * g + (0 if i == i0 else 2):3 * g + (2 if i == i0 else 3)]
+            if csum and i == i0:
+                for d, r in dots[2 * g:2 * g + 2]:
+                    L.append(f"v_dot2_f32_bf16 %[{d}], v{r}, %[ones], %[{d}]")
+        if g in DMA_GROUPS and diag != 3:
+            tn_piece(L, "a", DMA_GROUPS.index(g), slot)
+
+
+def tn_body(csum, diag=0):
+    L = ["s_mov_b32 %[sm], m0"]
+    for ks in range(4):  # the first fragments: A-lo and B (set p) of k-tile 0 in ring slot 0
+        for b in range(2):
+            L += tn_frag_reads("l", ks * 2 + b, f"a{'EO'[b]}0", ks * 2048)
+        for i in range(4):
+            L += tn_frag_reads("p", ks * 4 + i, f"b{'EO'[i & 1]}0", (i >> 1) * 8192 + ks * 2048)
+    L.append("1:")
+    tn_ktile(L, 0, "p", "q", csum, diag)
+    tn_ktile(L, 1, "q", "p", csum, diag)
+    L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %[sm]"]
+    return L
+
+
 def emit(name, lines):
     out = [f"#define {name} \\"]
     for l in lines:
@@ -116,6 +204,13 @@ def main():
     txt += f"#define W4_TILE_ADDRS {ad}\n"
     open(OUT, "w").write(txt)
     print("wrote", os.path.normpath(OUT), len(body()), "instructions")
+    # ---- TN
+    txt = "// GENERATED by tools/gen_gemm4w_ktile.py -- do not edit.  See that script for the schedule.\n"
+    txt += emit("W4T_TILE_ASM", tn_body(False)) + "\n" + emit("W4T_TILE_ASM_CSUM", tn_body(True))
+    txt += f"\n#define W4T_TILE_ACC {acc}\n"
+    txt += "#define W4T_TILE_CLOBBERS " + ", ".join(f'"v{r}"' for r in range(64, 256)) + "\n"
+    open(OUT.replace("gemm4w_ktile", "gemm4w_tn_ktile"), "w").write(txt)
+    print("wrote gemm4w_tn_ktile.inc", len(tn_body(True)), "instructions (with column sums)")
 
 
 if __name__ == "__main__":

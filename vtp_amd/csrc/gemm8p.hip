@@ -24,6 +24,7 @@
 //   first and retired by `lgkmcnt(8)` in front of phase 0's barrier.
 //   * dedicated 32 KiB epilogue staging (4 KiB per wave) beside the 128 KiB ring: 160 KiB = all of a CU's LDS, 1 workgroup / CU.
 #include "gemm_common.h"
+#include "gemm_group.h"
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -550,26 +551,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 // split-major over the XCDs like the flat split-K launches.  The slices of a tile are combined in the launch by the last arriver
 // (gemm8p_body), which also applies the epilogue (C = C + sum or C = sum, SwiGLU row de-interleave, fused bias-gradient column sums):
 // no slab buffers, no reduce launches, no separate column-sum launches.
-struct GroupProblem {  // 64-bit fields: written by the host as an int64 tensor
-  const bf16* A;
-  const bf16* B;
-  float* C;
-  float* colsum;
-  long lda, ldb, ldc;
-  long M, N;
-  long c_grp, c_pre;
-  long tile0;       // first tile of this problem in the launch's tile list
-  long accumulate;  // 1: C += result, 0: C = result
-  long pad[3];
-};
-struct GroupArgs {
-  const GroupProblem* probs;
-  float* part;
-  int* ticket;
-  int nprob, ntiles, splits, K, k_split;
-  unsigned long long* timing;
-};
-
 __global__ __launch_bounds__(512) void gemm8p_grouped_tn_kernel(const GroupArgs ga) {
   const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
   const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
@@ -732,18 +713,25 @@ int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 // One launch for the weight gradients of a transformer block (see gemm8p_grouped_tn_kernel).  probs: device array of `nprob`
 // GroupProblem records (16 x int64 each); ntiles = sum of their 256 x 256 tile counts; part / ticket: device scratch of
 // ntiles * splits * 256 KiB and ntiles ints (ticket zero-initialised by the caller once; the kernel leaves it zero).
-extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket,
-                                   void* stream) {
+namespace vtp {
+int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s);  // gemm4w_tn.hip
+}
+// kernel: 0 = the 8-phase kernel | 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip; the caller guarantees K % 8 == 0 and, as for
+// every grouped launch, M_g, N_g, lda, ldb multiples of 8 and operands within 32-bit byte offsets)
+extern "C" int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, int kernel,
+                                     void* stream) {
   using namespace vtp;
   VTP_REQUIRE(probs && nprob >= 1 && nprob <= 8, "vtp_gemm_tn_grouped: 1..8 problems");
   VTP_REQUIRE(ntiles >= 1 && K >= 1 && splits >= 1, "vtp_gemm_tn_grouped: bad shape (ntiles %d, K %d, splits %d)", ntiles, K, splits);
   VTP_REQUIRE(splits == 1 || (part && ticket), "vtp_gemm_tn_grouped: split-K needs the partial-sum and ticket buffers");
+  VTP_REQUIRE(kernel == 0 || (kernel == 1 && K % 8 == 0), "vtp_gemm_tn_grouped: kernel %d not available for K = %d", kernel, K);
   GroupArgs ga{};
   ga.probs = (const GroupProblem*)probs; ga.part = (float*)part; ga.ticket = (int*)ticket;
   ga.nprob = nprob; ga.ntiles = ntiles; ga.K = K;
   ga.k_split = ((K + splits - 1) / splits + 63) / 64 * 64;
   ga.splits = (K + ga.k_split - 1) / ga.k_split;
   ga.timing = g_p8_timing;
+  if (kernel == 1 && !ga.timing) return launch_gemm4w_grouped_tn(ga, (hipStream_t)stream);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm8p_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
@@ -751,6 +739,10 @@ extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int
   }
   hipLaunchKernelGGL(gemm8p_grouped_tn_kernel, dim3(ntiles * ga.splits), dim3(512), P8_LDS, (hipStream_t)stream, ga);
   return check_launch("gemm8p_grouped_tn");
+}
+extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket,
+                                   void* stream) {
+  return vtp_gemm_tn_grouped_k(probs, nprob, ntiles, K, splits, part, ticket, 0, stream);
 }
 
 // diagnostics for tools/gemm8p_timeline.py: `timing` = device buffer of [workgroups][16 tiles][4] u64 s_memrealtime stamps (100 MHz)

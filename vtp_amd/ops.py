@@ -174,6 +174,22 @@ def wgrad_group_splits(ntiles: int, Ktok: int):
     return ks, (Ktok + ks - 1) // ks
 
 
+def wgrad_group_kernel(ntiles: int, splits: int, Ktok: int) -> int:
+    """which kernel runs a grouped weight-gradient launch: 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip) when the token count allows
+    its 8-row staging pieces and a K slice is long enough to amortise its pipeline fill; 0 = the 8-phase kernel.  VTP_GEMM4W_TN=0 / 1
+    forces the choice (same-box A/B of the step)."""
+    import os
+    e = os.environ.get("VTP_GEMM4W_TN")
+    if Ktok % 8 != 0 or e == "0":
+        return 0
+    if e == "1":
+        return 1
+    return 1 if Ktok // max(splits, 1) >= W4_TN_MIN_SLICE else 0
+
+
+W4_TN_MIN_SLICE = 4096  # token rows per K slice from which the one-wave-per-SIMD kernel is taken (measured: tools/wgrad_group_bench.py)
+
+
 class WgradGroup:
     """The weight gradients of one transformer block as ONE launch (vtp_gemm_tn_grouped): problems dW_g[N_g, K_g] (+)= dy_g^T x_g
     over the same token rows.  add() the problems, finalize() once (the operand buffers are static: the device descriptor table
@@ -213,9 +229,12 @@ class WgradGroup:
             self.part, self.ticket = scratch["part"], scratch["ticket"]
         return self
 
-    def launch(self):
-        _lib.check(_lib_().vtp_gemm_tn_grouped(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.splits, _p(self.part),
-                                                _p(self.ticket), _s()), "vtp_gemm_tn_grouped")
+    def launch(self, kernel=None):
+        """kernel: 0 = the 8-phase kernel, 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip), None = the measured choice"""
+        if kernel is None:
+            kernel = wgrad_group_kernel(self.ntiles, self.splits, self.Ktok)
+        _lib.check(_lib_().vtp_gemm_tn_grouped_k(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.splits, _p(self.part),
+                                                  _p(self.ticket), kernel, _s()), "vtp_gemm_tn_grouped")
 
 
 def colsum_bf16(inp, ld, out, R, C, swiglu_h=0, in_remap=(0, 0)):
