@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   GemmArgs p{};
   p.A = pr.A; p.B = pr.B; p.C = pr.C; p.resid = pr.accumulate ? pr.C : nullptr; p.colsum = pr.colsum;
   p.M = (int)pr.M; p.N = (int)pr.N; p.K = ga.K; p.lda = (int)pr.lda; p.ldb = (int)pr.ldb; p.ldc = (int)pr.ldc;
-  p.c_grp = (int)pr.c_grp; p.c_pre = (int)pr.c_pre; p.k_split = ga.k_split; p.alpha = 1.f; p.xcd_swizzle = 0;
+  p.c_grp = (int)pr.c_grp; p.c_pre = (int)pr.c_pre; p.k_split = ga.k_split; p.alpha = 1.f;
+  p.xcd_swizzle = 2;  // (bit 1: the LDS-staged store path of the shared epilogue)
   const int lt = tile - (int)pr.tile0, tiles_n = (p.N + 255) >> 8;
   const int n0 = (lt % tiles_n) << 8, m0 = (lt / tiles_n) << 8;
   const int kbeg = zslice * ga.k_split;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int* flag = (int*)(smem + W4T_RING);
+    int* flag = (int*)(smem + W4T_LDS - 16);  // (outside the 4 KiB the epilogue stages through per wave)
     if (tid == 0) {
       const int t = __hip_atomic_fetch_add(ga.ticket + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = t == ga.splits - 1;
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
       if (z == zslice) continue;
       const f32x4* other = (const f32x4*)ga.part + (((size_t)tile * ga.splits + z) * 4 + wave) * 4096 + lane;
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        f32x4 v[16];
+      for (int gq = 0; gq < 8; ++gq) {
+        f32x4 v[8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = other[(gq * 16 + t) * 64];
+        for (int t = 0; t < 8; ++t) v[t] = other[(gq * 8 + t) * 64];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int u = gq * 16 + t;
+        for (int t = 0; t < 8; ++t) {
+          const int u = gq * 8 + t;
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[u >> 4][(u >> 2) & 3][4 * (u & 3) + e] += v[t][e];
         }
@@ -209,8 +210,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
       }
     }
   }
-  gemm_epilogue<EPI_F32, true, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[0], nullptr, m0, n0, wr, wc * 2, lane, zslice, nullptr);
-  gemm_epilogue<EPI_F32, true, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[2], nullptr, m0, n0, wr, wc * 2 + 1, lane, zslice, nullptr);
+  // C (+)= acc through the LDS-staged fp32 store path of the shared epilogue (full 128-B row segments, the rows of C read ahead; the
+  // fragment roles are those of the NT kernels, so the NT instantiation applies; element-wise the arithmetic of the direct path)
+  char* reg = smem + W4T_RING + wave * 8192;
+  gemm_epilogue<EPI_F32, false, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[0], reg, m0, n0, wr, wc * 2, lane, 0, nullptr);
+  gemm_epilogue<EPI_F32, false, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[2], reg, m0, n0, wr, wc * 2 + 1, lane, 0, nullptr);
 }
 
 // launcher used by vtp_gemm_tn_grouped (gemm8p.hip) when every problem fits this kernel (checked there: host copy of the records)
