@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvtp_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on", "-I", CSRC, "-I",
-         os.path.join(ROOT, "include")] + os.environ.get("VTP_HIPCC_EXTRA", "").split()  # e.g. -DVTP_P8_TWO_PHASE (experiment builds)
+         os.path.join(ROOT, "include")] + os.environ.get("VTP_HIPCC_EXTRA", "").split()  # e.g. -DVTP_P8_FOUR_PHASE (A/B builds)
 
 
 def _sources():

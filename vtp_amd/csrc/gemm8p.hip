@@ -14,8 +14,11 @@
 //     with ds_read_b64_tr_b16.  Each wave issues 2 LDS-DMA pieces (global_load_lds_dwordx4, 1 KiB) per half-tile.
 //   * ring of 8 half-tile slots (2 k-tiles); the staging cursor runs 7 half-tiles ahead of the compute cursor, ACROSS output
 //     tiles (persistent workgroups: the next tile's operands stream in under the current tile's last k-tiles and epilogue).
-//   * one k-tile = 4 phases; phase p = { fragment reads of p | LDS-DMA issue of half-tile g + 7 | s_barrier | 8 MFMAs (one
-//     64 x 32 quadrant of the wave tile x k = 64) | s_barrier }.  The two wave groups run ONE barrier apart (group 1 executes
+//   * one k-tile = 2 phases (round 4; -DVTP_P8_FOUR_PHASE builds the earlier four-phase schedule the file name comes from: 8 barrier
+//     intervals per k-tile); phase A = { reads of B-first, A-first, B-second | DMA issue | s_barrier | 16 MFMAs (rows 0..63 of the wave
+//     tile x k = 64) | s_barrier }, phase B = { reads of A-second | 3 DMA issues | s_barrier | 16 MFMAs | s_barrier }
+//     [four-phase: phase p = { fragment reads of p | LDS-DMA issue of half-tile g + 7 | s_barrier | 8 MFMAs (one 64 x 32 quadrant of
+//     the wave tile x k = 64) | s_barrier }].  The two wave groups run ONE barrier apart (group 1 executes
 //     one extra barrier in front of a tile's k loop, group 0 one behind it), so on every SIMD one wave is in its MFMA segment
 //     while its partner reads LDS / issues DMA: the matrix pipe is never shared and never idle for longer than a barrier.
 //   * `s_waitcnt vmcnt(6)` once per k-tile (phase 3): every half-tile of the next k-tile has landed, 3 stay in flight.
@@ -362,8 +365,10 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         p.timing[(size_t)(gridDim.x + blockIdx.x) * 64 + kt] = wall_clock64();
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       Frags b1, b2, a1[2], a2[2];
-#ifdef VTP_P8_TWO_PHASE
-      // EXPERIMENT: two phases of 16 MFMAs per k-tile instead of four of 8 (half as many barrier intervals per k-tile).
+#ifndef VTP_P8_FOUR_PHASE
+      // Two phases of 16 MFMAs per k-tile (the schedule in use since round 4: half as many barrier intervals per k-tile as the four
+      // phases of 8 MFMAs below; measured 1-3 % per launch, +0.3 % on the step in three of three same-box repetitions,
+      // profiles/r04_2ph_step_ab.log).  The two wave groups still run one barrier apart.
       // ---- phase A: B-first, A-first, B-second -> quadrants (cols 0..63, rows 0..63); issues A-second of the next k-tile
       load_b(kb, b1);
       load_a(kb + P8_SLOT, a1);
