@@ -492,10 +492,10 @@ def main():
 
     orig_grp = ops.WgradGroup.launch
 
-    def timed_grp(self):  # the block's grouped weight-gradient launch: sum of 2 N K tokens over its problems
+    def timed_grp(self, kernel=None):  # the block's grouped weight-gradient launch: sum of 2 N K tokens over its problems
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig_grp(self)
+        orig_grp(self, kernel)
         e1.record()
         fl = sum(2.0 * r[7] * r[8] * self.Ktok for r in self.rows)
         by = sum(2.0 * self.Ktok * (r[7] + r[8]) + 4.0 * r[7] * r[8] * (2 if r[12] else 1) for r in self.rows)  # dy + x read, dW written (+ read: C +=)
@@ -540,7 +540,7 @@ def main():
             try:  # HBM bytes per launch and SQ counters of the same kernels from the committed rocprofv3 --pmc passes of this command
                 d = json.load(open(pmc))
                 by, n, busy, gui = 0.0, 0, 0.0, 0.0
-                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn", "gemm8h_nt"):
+                for fam in ("gemm_nt", "gemm_tn", "gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn", "gemm8h_nt", "gemm4w_nt", "gemm4w_grouped_tn"):
                     if fam not in d:
                         continue
                     # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B (x2, MI355X_MICROARCH.md HBM)
@@ -555,13 +555,13 @@ def main():
                     # summed over the 8 XCDs; 1024 SIMDs); attention alongside, from the same pass
                     mfma_util = round(busy / (gui / 8.0 * 1024.0), 4)
                     pmc_extra = {k: {m: d[k][m] for m in ("mfma_util", "valu_busy", "lds_bank_conflict_frac") if m in d[k]}
-                                 for k in ("gemm8p_nt", "gemm8h_nt", "gemm8p_grouped_tn", "gemm_nt", "attn_fwd", "attn_bwd_fused") if k in d}
+                                 for k in ("gemm8p_nt", "gemm8h_nt", "gemm4w_nt", "gemm4w_grouped_tn", "gemm8p_grouped_tn", "gemm_nt", "attn_fwd", "attn_bwd_fused") if k in d}
             except (KeyError, ValueError, ZeroDivisionError):
                 pass
         # algorithmic HBM bytes of the same launches: every operand read once, every result written once (+ the residual / pre-
         # activation reads of the fused epilogues) -- what `traffic` is to be compared with
         alg = sum(r[4] for r in recs if len(r) > 4 and r[4])
-        roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm8p_grouped_tn_kernel + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad, TN wgrad incl. the per-block grouped launches, 256x256 8-phase and ring tile configs, all epilogues)",
+        roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm4w_grouped_tn_kernel + vtp::gemm4w_kernel<...> + vtp::gemm8h_kernel<...> + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad, TN wgrad incl. the per-block grouped launches; 256x256 8-phase, one-wave-per-SIMD and 128x256 kernels, ring tile configs, all epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch_avg": round(alg / len(recs)) if alg else None,

@@ -400,3 +400,37 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
     assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["OMP_NUM_THREADS"] == str(max(1, (os.cpu_count() or 8) // 8))
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_grouped_wgrad_kernel_choice(monkeypatch):
+    """ops.wgrad_group_kernel: the one-wave-per-SIMD kernel (gemm4w_tn.hip) needs token counts that are multiples of 8 (its LDS-DMA pieces
+    are 8 k rows, zero-filled as a whole beyond the slice) and K slices of >= 1024 rows (profiles/r04_wgrad_kernel_ab.log); the
+    environment switch of the same-box step A/B overrides the measured rule but never the multiple-of-8 requirement"""
+    from vtp_amd import ops
+    monkeypatch.delenv("VTP_GEMM4W_TN", raising=False)
+    assert ops.wgrad_group_kernel(108, 2, 34144) == 1 and ops.wgrad_group_kernel(196, 1, 8192) == 1 and ops.wgrad_group_kernel(108, 2, 2464) == 1
+    assert ops.wgrad_group_kernel(108, 2, 2134) == 0      # 2134 % 8 != 0
+    assert ops.wgrad_group_kernel(24, 4, 2048) == 0       # 512-row slices
+    monkeypatch.setenv("VTP_GEMM4W_TN", "0")
+    assert ops.wgrad_group_kernel(108, 2, 34144) == 0
+    monkeypatch.setenv("VTP_GEMM4W_TN", "1")
+    assert ops.wgrad_group_kernel(24, 4, 2048) == 1 and ops.wgrad_group_kernel(108, 2, 2134) == 0
+
+
+def test_generated_k_loops_are_up_to_date(tmp_path, monkeypatch):
+    """vtp_amd/csrc/gemm4w_ktile.inc / gemm4w_tn_ktile.inc are GENERATED (tools/gen_gemm4w_ktile.py) and committed: the committed text
+    must be what the generator writes (an edit of the schedule that forgets to regenerate -- or a hand edit of the .inc -- fails here)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen4w", os.path.join(root, "tools", "gen_gemm4w_ktile.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    monkeypatch.setattr(gen, "OUT", str(tmp_path / "gemm4w_ktile.inc"))
+    gen.main()
+    for name in ("gemm4w_ktile.inc", "gemm4w_tn_ktile.inc"):
+        assert (tmp_path / name).read_text() == open(os.path.join(root, "vtp_amd", "csrc", name)).read(), name
+    body = gen.body()
+    assert sum("v_mfma" in l for l in body) == 128 and sum("global_load_lds" in l for l in body) == 32 and sum("s_barrier" in l for l in body) == 4
+    tn = gen.tn_body(True)
+    assert sum("v_mfma" in l for l in tn) == 128 and sum("ds_read_b64_tr_b16" in l for l in tn) == 48 + 128 and sum("v_dot2" in l for l in tn) == 128

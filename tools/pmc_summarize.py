@@ -11,6 +11,10 @@ from collections import defaultdict
 def family(name: str) -> str:
     name = re.sub(r"^void ", "", name)
     m = re.match(r"(?:vtp::)?(\w+)", name.replace("_ZN3vtp", ""))
+    if "gemm4w_grouped_tn_kernel" in name:
+        return "gemm4w_grouped_tn"
+    if "gemm4w_kernel" in name:
+        return "gemm4w_nt"
     if "gemm8p_grouped_tn_kernel" in name:
         return "gemm8p_grouped_tn"
     if "gemm8h_kernel" in name:
@@ -55,7 +59,7 @@ def rederive(src, out):
     for fam, d in res.items():
         d.update(derived({c: v["sum"] for c, v in d.items() if isinstance(v, dict)}))
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for fam in ("gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn", "gemm8h_nt", "gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd_fused", "norm_bwd", "adamw"):
+    for fam in ("gemm8p_nt", "gemm8p_tn", "gemm8p_grouped_tn", "gemm4w_grouped_tn", "gemm4w_nt", "gemm8h_nt", "gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd_fused", "norm_bwd", "adamw"):
         if fam in res:
             print(fam, {k: v for k, v in res[fam].items() if not isinstance(v, dict)})
 
