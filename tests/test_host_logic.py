@@ -404,11 +404,12 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
 
 def test_grouped_wgrad_kernel_choice(monkeypatch):
     """ops.wgrad_group_kernel: the one-wave-per-SIMD kernel (gemm4w_tn.hip) needs token counts that are multiples of 8 (its LDS-DMA pieces
-    are 8 k rows, zero-filled as a whole beyond the slice) and K slices of >= 1024 rows (profiles/r04_wgrad_kernel_ab.log); the
+    are 8 k rows, zero-filled as a whole beyond the slice) and K slices of >= 4096 rows (profiles/r04_wgrad_kernel_ab.log); the
     environment switch of the same-box step A/B overrides the measured rule but never the multiple-of-8 requirement"""
     from vtp_amd import ops
     monkeypatch.delenv("VTP_GEMM4W_TN", raising=False)
-    assert ops.wgrad_group_kernel(108, 2, 34144) == 1 and ops.wgrad_group_kernel(196, 1, 8192) == 1 and ops.wgrad_group_kernel(108, 2, 2464) == 1
+    assert ops.wgrad_group_kernel(108, 2, 34144) == 1 and ops.wgrad_group_kernel(196, 1, 8192) == 1 and ops.wgrad_group_kernel(108, 2, 8192) == 1
+    assert ops.wgrad_group_kernel(108, 2, 2464) == 0      # 1232-row slices: the 8-phase kernel
     assert ops.wgrad_group_kernel(108, 2, 2134) == 0      # 2134 % 8 != 0
     assert ops.wgrad_group_kernel(24, 4, 2048) == 0       # 512-row slices
     monkeypatch.setenv("VTP_GEMM4W_TN", "0")

@@ -187,7 +187,7 @@ def wgrad_group_kernel(ntiles: int, splits: int, Ktok: int) -> int:
     return 1 if Ktok // max(splits, 1) >= W4_TN_MIN_SLICE else 0
 
 
-W4_TN_MIN_SLICE = 1024  # token rows per K slice from which the one-wave-per-SIMD kernel is taken (tools/wgrad_kernel_ab.py: x1.01 at 1232 rows .. x1.12 at 17072)
+W4_TN_MIN_SLICE = 4096  # token rows per K slice from which the one-wave-per-SIMD kernel is taken (tools/wgrad_kernel_ab.py against the two-phase 8-phase kernel: x0.97 at 1232 .. 2048 rows, x1.01 at 4096, x1.06 at 8224, x1.08 .. 1.12 at 17072)
 
 
 class WgradGroup:
