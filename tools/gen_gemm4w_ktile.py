@@ -95,7 +95,7 @@ def body(diag=0):
 # ------------------------------------------------------------------------------------------------------------------------------------
 # TN (weight gradient: C = A^T B, A [K, M], B [K, N], k along the rows of both operands).  Same X / Y schedule; what differs:
 #   * a staged k-tile = eight 8-KiB sub-images [64 k][64 columns] (128-B rows: A columns wr*128 + {0..63 | 64..127}, B likewise; the
-#     16-B chunk index of k-row r is XORed with 4 (r & 1)); wave w stages A sub-image w and B sub-image w: 8 pieces of 8 k-rows;
+#     16-B chunk index of k-row r is XORed with 4 ((r >> 1) & 1)); wave w stages A sub-image w and B sub-image w: 8 pieces of 8 k-rows;
 #     the pieces' k-rows beyond the slice's K range read a zero block instead (per-piece scalar select)
 #   * a fragment = two ds_read_b64_tr_b16 (k rows +0 and +4) -> the fragment registers are PHYSICAL (v64..v255: an asm operand cannot
 #     name half of a register quadruple); the first fragments are read inside the asm

@@ -5,8 +5,9 @@
 //
 //   * 4 waves = 2 (M) x 2 (N), wave tile 128 x 128, 256 accumulator AGPRs, fragments in PHYSICAL VGPRs v64..v255 (the asm owns them);
 //   * a staged k-tile (64 k rows) = eight 8-KiB sub-images [64 k][64 columns] with 128-B rows -- A columns wr * 128 + {0..63 | 64..127},
-//     B columns wc * 128 + {0..63 | 64..127} -- whose 16-B chunk index is XORed with 4 (k & 1): the eight k rows one
-//     ds_read_b64_tr_b16 touches spread over both 64-B halves of the bank window;
+//     B columns wc * 128 + {0..63 | 64..127} -- whose 16-B chunk index is XORed with 4 ((k >> 1) & 1): the eight k rows one
+//     ds_read_b64_tr_b16 touches (k0 + {0..3, 8..11}, 64 B each) then cover the four 64-B positions of the 256-B bank window (two k
+//     rows of 128 B) twice each.  (XOR 4 (k & 1) left half the banks idle: 49 % of the LDS cycles were conflict cycles.)
 //   * wave w stages A sub-image w (in the Y step) and B sub-image w (in the X step): 8 LDS-DMA pieces of 8 k rows each; pieces whose k
 //     rows lie beyond the slice read a zero block (so a slice needs no K-tail path, and an odd k-tile count is padded with a zero one);
 //   * ring of two k-tiles (128 KiB) + 32 KiB: publish flag of the combine; 160 KiB, one workgroup per CU.
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
 
   // ---------------------------------------------------------------- staging: wave w = A sub-image w and B sub-image w of every k-tile
   // piece i (0..7) = k rows 8 i + (lane >> 3) of the k-tile; the lane's 16-B chunk slot lane & 7 holds source chunk
-  // (lane & 7) ^ 4 ((lane >> 3) & 1); columns beyond the matrix are clamped (they only feed outputs the epilogue masks)
-  const int krow = lane >> 3, chunk = (lane & 7) ^ (4 * (krow & 1));
+  // (lane & 7) ^ 4 ((lane >> 4) & 1); columns beyond the matrix are clamped (they only feed outputs the epilogue masks)
+  const int krow = lane >> 3, chunk = (lane & 7) ^ (4 * ((krow >> 1) & 1));
   const int cola = min(m0 + wave * 64 + chunk * 8, p.M - 8), colb = min(n0 + wave * 64 + chunk * 8, p.N - 8);
   unsigned pea = (unsigned)(((size_t)(kbeg + krow) * p.lda + cola) * 2), peb = (unsigned)(((size_t)(kbeg + krow) * p.ldb + colb) * 2);
   const unsigned zoff = (lane & 3) * 16;
@@ -124,11 +125,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
 
   // ---------------------------------------------------------------- fragment reads (ds_read_b64_tr_b16: see tools/gen_gemm4w_ktile.py)
   // the lane addresses 4 consecutive columns (8 B) of k row hi * 8 + t_rq of a 16-row k-step; 32-column block b of a sub-image
-  // = chunks 4 b + [0, 4), swizzled with the row's parity
+  // = chunks 4 b + [0, 4), swizzled with bit 1 of the k row
   unsigned aE[2], aO[2], bE[2], bO[2];
   {
     const int t_li = lane & 15, t_rq = t_li >> 2;
-    const int cq = ((lane >> 4) & 1) * 2 + ((t_li & 3) >> 1), sz = 4 * (t_rq & 1);
+    const int cq = ((lane >> 4) & 1) * 2 + ((t_li & 3) >> 1), sz = 4 * ((t_rq >> 1) & 1);
     const unsigned rowb = (unsigned)((hi * 8 + t_rq) * 128 + (t_li & 1) * 8);
     const unsigned lb0 = rowb + (unsigned)(((0 + cq) ^ sz) << 4), lb1 = rowb + (unsigned)(((4 + cq) ^ sz) << 4);
 #pragma unroll
