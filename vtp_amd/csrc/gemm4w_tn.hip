@@ -15,8 +15,6 @@
 #include "gemm_common.h"
 #include "gemm_group.h"
 #include "gemm4w_tn_ktile.inc"
-#include <cstdio>
-#include <cstdlib>
 
 namespace vtp {
 
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm4w_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm4w_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4T_LDS);
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm4w_grouped_tn_kernel, dim3(ga.ntiles * ga.splits), dim3(256), W4T_LDS, s, ga);
