@@ -111,10 +111,17 @@ def tn_frag_reads(kind, idx, addr, off):
     return [f"ds_read_b64_tr_b16 v[{r}:{r + 1}], %[{addr}] offset:{off}", f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], %[{addr}] offset:{off + 512}"]
 
 
-def tn_piece(L, which, n, slot):
+def tn_piece_head(L, which):
+    """valid / zero-block selection of a piece, at the HEAD of its group: two MFMAs ahead of the load that consumes the selected base
+    and offset (an SALU-written SGPR needs wait states before a VMEM instruction reads it, and the chain s_cmp -> s_cselect ->
+    v_cndmask in front of the load stalled the in-order issue)"""
     L += [f"s_cmp_gt_i32 %[kr{which}], 0", f"s_cselect_b64 %[sb], %[mat{which}], %[zb]", "s_cselect_b64 vcc, -1, 0",
-          f"v_cndmask_b32 %[vt], %[zoff], %[pe{which}], vcc", f"global_load_lds_dwordx4 %[vt], %[sb]",
-          f"v_add_u32 %[pe{which}], %[step{which}], %[pe{which}]", f"s_sub_u32 %[kr{which}], %[kr{which}], 8"]
+          f"v_cndmask_b32 %[vt], %[zoff], %[pe{which}], vcc"]
+
+
+def tn_piece(L, which, n, slot):
+    L += [f"global_load_lds_dwordx4 %[vt], %[sb]", f"v_add_u32 %[pe{which}], %[step{which}], %[pe{which}]",
+          f"s_sub_u32 %[kr{which}], %[kr{which}], 8"]
 
 
 def tn_ktile(L, slot, bc, bn, csum, diag):
@@ -131,6 +138,7 @@ def tn_ktile(L, slot, bc, bn, csum, diag):
         j, i0 = q >> 1, (q & 1) * 2
         if g in DMA_GROUPS and diag != 3:
             L.append(f"s_mov_b32 m0, %[db{slot}]" if g == 0 else "s_add_u32 m0, m0, 0x400")
+            tn_piece_head(L, "b")
         for i in (i0, i0 + 1):
             rb, ra = FR(bc, ks * 4 + i), FR("l", ks * 2 + j)
             L.append(f"v_mfma_f32_32x32x16_bf16 %[c{i}{j}], v[{rb}:{rb + 3}], v[{ra}:{ra + 3}], %[c{i}{j}]")
@@ -155,6 +163,7 @@ def tn_ktile(L, slot, bc, bn, csum, diag):
         j, i0 = q >> 1, (q & 1) * 2
         if g in DMA_GROUPS and diag != 3:
             L.append(f"s_mov_b32 m0, %[da{slot}]" if g == 0 else "s_add_u32 m0, m0, 0x400")
+            tn_piece_head(L, "a")
         for i in (i0, i0 + 1):
             rb, ra = FR(bc, ks * 4 + i), FR("h", ks * 2 + j)
             L.append(f"v_mfma_f32_32x32x16_bf16 %[c{i}{2 + j}], v[{rb}:{rb + 3}], v[{ra}:{ra + 3}], %[c{i}{2 + j}]")
