@@ -32,6 +32,16 @@ __device__ __forceinline__ void w4t_glds16(const char* sbase, unsigned voff, uns
                : "memory");
 }
 
+// wave-uniform values that reach us through vector loads (the problem records are read inside the stream-K segment loop, where hipcc
+// cannot use scalar loads): back into SGPRs, as the asm operands need them
+__device__ __forceinline__ int w4t_uni(long v) { return __builtin_amdgcn_readfirstlane((int)v); }
+template <class T>
+__device__ __forceinline__ T* w4t_uni(T* v) {
+  const unsigned long long u = (unsigned long long)v;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 struct W4TStage {  // wave-uniform staging constants
   const char *mata, *matb, *zb;
   unsigned stepa, stepb, da[2], db[2];
@@ -63,7 +73,10 @@ __device__ __forceinline__ void w4t_kloop(f32x16 (&acc)[4][4], float (&cs)[4], c
   }
 }
 
-__global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupArgs ga) {
+// one (tile, K range) of a grouped launch: k rows [kbeg, kbeg + kcount) of the tile's reduction; `nparts` workgroups share the tile and
+// this one is number `part` of them (slot of its partial sums; nparts == 1: no combine).  Returns after the tile's epilogue if this
+// workgroup arrived last, after the publish otherwise.
+__device__ __forceinline__ void w4t_segment(const GroupArgs& ga, int tile, int kbeg, int kcount, int nparts, int part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,23 +84,18 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   const int wr = wave >> 1, wc = wave & 1;
   const int hi = lane >> 5;
 
-  // (tile, K slice) of this workgroup: split-major over the XCDs, as gemm8p_grouped_tn_kernel
-  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
-  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
-  const int zslice = c / ga.ntiles, tile = c - zslice * ga.ntiles;
   int g = 0;
   for (int i = 1; i < ga.nprob; ++i)
     if ((int)ga.probs[i].tile0 <= tile) g = i;
   const GroupProblem& pr = ga.probs[g];
   GemmArgs p{};
-  p.A = pr.A; p.B = pr.B; p.C = pr.C; p.resid = pr.accumulate ? pr.C : nullptr; p.colsum = pr.colsum;
-  p.M = (int)pr.M; p.N = (int)pr.N; p.K = ga.K; p.lda = (int)pr.lda; p.ldb = (int)pr.ldb; p.ldc = (int)pr.ldc;
-  p.c_grp = (int)pr.c_grp; p.c_pre = (int)pr.c_pre; p.k_split = ga.k_split; p.alpha = 1.f;
+  p.A = w4t_uni(pr.A); p.B = w4t_uni(pr.B); p.C = w4t_uni(pr.C); p.resid = w4t_uni(pr.accumulate) ? (const float*)p.C : nullptr;
+  p.colsum = w4t_uni(pr.colsum);
+  p.M = w4t_uni(pr.M); p.N = w4t_uni(pr.N); p.K = ga.K; p.lda = w4t_uni(pr.lda); p.ldb = w4t_uni(pr.ldb); p.ldc = w4t_uni(pr.ldc);
+  p.c_grp = w4t_uni(pr.c_grp); p.c_pre = w4t_uni(pr.c_pre); p.k_split = ga.k_split; p.alpha = 1.f;
   p.xcd_swizzle = 2;  // (bit 1: the LDS-staged store path of the shared epilogue)
-  const int lt = tile - (int)pr.tile0, tiles_n = (p.N + 255) >> 8;
+  const int lt = tile - w4t_uni(pr.tile0), tiles_n = (p.N + 255) >> 8;
   const int n0 = (lt % tiles_n) << 8, m0 = (lt / tiles_n) << 8;
-  const int kbeg = zslice * ga.k_split;
-  const int kcount = min(ga.K, kbeg + ga.k_split) - kbeg;
   const unsigned nk2 = (unsigned)((kcount + 127) >> 7);  // pairs of k-tiles (an odd count is padded with an all-zero k-tile)
 
   // ---------------------------------------------------------------- staging: wave w = A sub-image w and B sub-image w of every k-tile
@@ -164,11 +172,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
       if (hi == 0 && m < p.M) unsafeAtomicAdd(p.colsum + remap_row(m, p.c_grp, p.c_pre), v);
     }
   }
-  if (ga.splits > 1) {
-    // split-K combine inside the launch (the protocol of gemm8p_body): publish the accumulators fragment-major with write-through
+  if (nparts > 1) {
+    // combine inside the launch (the protocol of gemm8p_body): publish the accumulators fragment-major with write-through
     // stores -> drain -> barrier -> ticket; the last arriver adds the other slices' partials in slice order and runs the epilogue
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-    const f32x4* mine = (const f32x4*)ga.part + (((size_t)tile * ga.splits + zslice) * 4 + wave) * 4096;
+    const f32x4* mine = (const f32x4*)ga.part + (((size_t)tile * ga.splits + part) * 4 + wave) * 4096;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, 4096 * 16, 0x00020000);
 #pragma unroll
     for (int u = 0; u < 64; ++u) {
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
     int* flag = (int*)(smem + W4T_LDS - 16);  // (outside the 4 KiB the epilogue stages through per wave)
     if (tid == 0) {
       const int t = __hip_atomic_fetch_add(ga.ticket + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = t == ga.splits - 1;
+      const int last = t == nparts - 1;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(ga.ticket + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -191,8 +199,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
     }
     __syncthreads();
     if (*flag == 0) return;
-    for (int z = 0; z < ga.splits; ++z) {
-      if (z == zslice) continue;
+    for (int z = 0; z < nparts; ++z) {
+      if (z == part) continue;
       const f32x4* other = (const f32x4*)ga.part + (((size_t)tile * ga.splits + z) * 4 + wave) * 4096 + lane;
 #pragma unroll
       for (int gq = 0; gq < 8; ++gq) {
@@ -216,6 +224,42 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   gemm_epilogue<EPI_F32, false, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[2], reg, m0, n0, wr, wc * 2 + 1, lane, 0, nullptr);
 }
 
+
+// one workgroup per (tile, K slice): the launch geometry of gemm8p_grouped_tn_kernel (tiles x splits workgroups, split-major over the XCDs)
+__global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupArgs ga) {
+  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
+  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+  const int zslice = c / ga.ntiles, tile = c - zslice * ga.ntiles;
+  const int kbeg = zslice * ga.k_split;
+  w4t_segment(ga, tile, kbeg, min(ga.K, kbeg + ga.k_split) - kbeg, ga.splits, zslice);
+}
+
+// stream-K: the launch's reduction work -- ntiles x U units of 128 k rows (U = units per tile) -- is cut into gridDim.x EQUAL contiguous
+// ranges, one per CU, instead of tiles x splits slices that leave CUs idle (108 tiles x 2 slices = 216 of 256; 196 x 1 = 196).  A
+// range spans at most a few tiles; per tile the workgroups whose ranges touch it are its parts (numbered in range order), combined in
+// the launch exactly like K slices.  ga.splits = the partial-sum slots per tile the caller allocated (>= the largest part count).
+__global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_streamk_kernel(const GroupArgs ga) {
+  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
+  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);  // XCD x owns a contiguous chunk of ranges
+  const int U = (ga.K + 127) >> 7;
+  const int total = ga.ntiles * U;  // (< 2^31: checked by the launcher)
+  const int Q = (total + W - 1) / W;
+  int u = c * Q;
+  const int end = min(u + Q, total);
+  bool first = true;
+  while (u < end) {
+    // (wave-uniform by construction; readfirstlane because the integer divisions are computed on the vector ALU)
+    const int tile = __builtin_amdgcn_readfirstlane(u / U);
+    const int k0 = u - tile * U;
+    const int len = min(U - k0, end - u);
+    const int p_first = __builtin_amdgcn_readfirstlane((tile * U) / Q), p_last = __builtin_amdgcn_readfirstlane(((tile + 1) * U - 1) / Q);
+    if (!first) __syncthreads();  // the previous segment's epilogue staging / flag word are done with
+    first = false;
+    w4t_segment(ga, tile, k0 * 128, min(ga.K - k0 * 128, len * 128), p_last - p_first + 1, c - p_first);
+    u += len;
+  }
+}
+
 // launcher used by vtp_gemm_tn_grouped (gemm8p.hip) when every problem fits this kernel (checked there: host copy of the records)
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   static bool attr_set = false;
@@ -225,6 +269,35 @@ int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   }
   hipLaunchKernelGGL(gemm4w_grouped_tn_kernel, dim3(ga.ntiles * ga.splits), dim3(256), W4T_LDS, s, ga);
   return check_launch("gemm4w_grouped_tn");
+}
+
+// number of workgroups of the stream-K launch (= CUs, a multiple of the 8 XCDs)
+int gemm4w_streamk_grid() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;  // (host-only callers: MI355X)
+    cus = prop.multiProcessorCount - prop.multiProcessorCount % 8;
+    if (cus < 8) cus = 8;
+  }
+  return cus;
+}
+
+int launch_gemm4w_grouped_tn_streamk(const GroupArgs& ga, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm4w_grouped_tn_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4T_LDS);
+    attr_set = true;
+  }
+  const long total = (long)ga.ntiles * ((ga.K + 127) / 128);
+  if (total >= (1l << 30)) {
+    set_error("gemm4w stream-K: %ld work units exceed the 32-bit range arithmetic", total);
+    return VTP_ERR_ARG;
+  }
+  const int W = gemm4w_streamk_grid();
+  hipLaunchKernelGGL(gemm4w_grouped_tn_streamk_kernel, dim3(total < W ? (int)total : W), dim3(256), W4T_LDS, s, ga);
+  return check_launch("gemm4w_grouped_tn_streamk");
 }
 
 }  // namespace vtp
