@@ -72,11 +72,6 @@ int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int spl
 /* the same launch with the kernel named: 0 = the 8-phase kernel (= vtp_gemm_tn_grouped), 1 = the one-wave-per-SIMD kernel with the
  * hand-scheduled k loop (needs K % 8 == 0; bit-identical results per K slice) */
 int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, int kernel, void* stream);
-/* kernel = 2 of vtp_gemm_tn_grouped_k: the one-wave-per-SIMD kernel as a STREAM-K launch -- one workgroup per CU, the launch's
- * reduction work (ntiles x ceil(K / 128) units) cut into equal contiguous ranges, the workgroups whose ranges touch a tile combined in
- * the launch like K slices.  `splits` is then the number of partial-sum slots per tile in `part` (ntiles * splits * 65536 floats) and
- * must be >= vtp_gemm_tn_grouped_slots(ntiles, K) (host-only query; depends on the device's CU count). */
-int vtp_gemm_tn_grouped_slots(int ntiles, int K);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);

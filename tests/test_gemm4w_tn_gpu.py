@@ -1,6 +1,4 @@
-"""(kernel = 2: the same kernel as a stream-K launch -- one workgroup per CU, equal contiguous ranges of the reduction work -- checked
-against torch and against the 8-phase kernel within the bound of a different summation order.)
-The grouped weight-gradient launch on the one-wave-per-SIMD kernel (vtp_amd/csrc/gemm4w_tn.hip + gemm4w_tn_ktile.inc, `kernel = 1` of
+"""The grouped weight-gradient launch on the one-wave-per-SIMD kernel (vtp_amd/csrc/gemm4w_tn.hip + gemm4w_tn_ktile.inc, `kernel = 1` of
 vtp_gemm_tn_grouped_k) -- against fp32 torch on the bf16 operands, and against the 8-phase kernel (`kernel = 0`): BIT FOR BIT where the
 launch has one K slice (same k order per output element, same MFMA, same epilogue), within the run-to-run bound of the in-launch combine
 where it has several (the last-arriving slice differs from run to run, in both kernels).  K tails inside a k-tile, odd k-tile counts
@@ -39,7 +37,7 @@ def test_grouped_wgrad_one_wave_kernel(Ktok, D, H):
     gw0 = [torch.randn(N * K, device=DEV, generator=g) for _, _, N, K, _, _ in probs]
     gb0 = [torch.randn(N, device=DEV, generator=g) if cs else None for _, _, N, _, _, cs in probs]
     res = {}
-    for kernel in (2, 1, 0):
+    for kernel in (1, 0):
         gws = [t.clone() for t in gw0]
         gbs = [None if t is None else t.clone() for t in gb0]
         grp = o.WgradGroup(Ktok)
@@ -71,10 +69,6 @@ def test_grouped_wgrad_one_wave_kernel(Ktok, D, H):
             assert float((gw1 - gw8).abs().max()) <= 2e-5 * float(gw8.abs().max())
         if cs:
             check(res[1][1][n], b0 + 2 * col, f"one-wave grouped db N={N}", bf16_out=False, scale=1e-4)
-            check(res[2][1][n], b0 + 2 * col, f"stream-K grouped db N={N}", bf16_out=False, scale=1e-4)
-        # the stream-K launch cuts the reduction at other places: same sums in another association
-        check(res[2][0][n].view(N, K), w0.view(N, K) + 2 * ref, f"stream-K grouped dW N={N} K={K}", bf16_out=False, scale=1e-4)
-        assert float((res[2][0][n] - gw8).abs().max()) <= 4e-5 * float(gw8.abs().max())
 
 
 def test_grouped_wgrad_one_wave_overwrite_forced_splits_and_refusal():

@@ -27,7 +27,7 @@ def main():
             for (a, x, N, K, sh, _), gw, gb in zip(probs, gws, gbs):
                 grp.add(a, x, gw, gb, N, K, sh)
             grp.finalize(dev, {})
-            t = timeit({"k8": lambda: grp.launch(kernel=0), "k4w": lambda: grp.launch(kernel=1), "ksk": lambda: grp.launch(kernel=2)})
+            t = timeit({"k8": lambda: grp.launch(kernel=0), "k4w": lambda: grp.launch(kernel=1)})
             fl = sum(2.0 * N * K * Ktok for _, _, N, K, _, _ in probs)
             more = ""
             for sp in [int(x) for x in os.environ.get("MORE_SPLITS", "").split()]:  # the one-wave kernel with other slice counts
@@ -36,13 +36,12 @@ def main():
                     g2.add(a, x, gw, gb, N, K, sh)
                 g2.finalize(dev, {})
                 g2.splits = sp
-                g2.part = torch.empty(g2.ntiles * max(sp, g2.slots) * 65536, device=dev)
+                g2.part = torch.empty(g2.ntiles * sp * 65536, device=dev)
                 g2.ticket = torch.zeros(max(g2.ntiles, 256), dtype=torch.int32, device=dev)
                 tt = timeit({"x": lambda: g2.launch(kernel=1)})["x"]
                 more += f" | one-wave x{sp} slices {tt:7.1f} us"
             print(f"D={D} Ktok={Ktok:5d} ({grp.ntiles:3d} tiles x {grp.splits} slices): 8-phase {t['k8']:7.1f} us {fl / t['k8'] / 1e6:7.1f} TF/s | "
-                  f"one-wave {t['k4w']:7.1f} us {fl / t['k4w'] / 1e6:7.1f} TF/s  x{t['k8'] / t['k4w']:.2f} | stream-K ({grp.slots} slots) {t['ksk']:7.1f} us "
-                  f"{fl / t['ksk'] / 1e6:7.1f} TF/s  x{t['k8'] / t['ksk']:.2f}  [auto: kernel {grp.kernel}]" + more, flush=True)
+                  f"one-wave {t['k4w']:7.1f} us {fl / t['k4w'] / 1e6:7.1f} TF/s  x{t['k8'] / t['k4w']:.2f}  [auto: kernel {grp.kernel}]" + more, flush=True)
 
 
 if __name__ == "__main__":

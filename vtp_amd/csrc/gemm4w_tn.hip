@@ -32,8 +32,8 @@ __device__ __forceinline__ void w4t_glds16(const char* sbase, unsigned voff, uns
                : "memory");
 }
 
-// wave-uniform values that reach us through vector loads (the problem records are read inside the stream-K segment loop, where hipcc
-// cannot use scalar loads): back into SGPRs, as the asm operands need them
+// wave-uniform values of the problem record: pinned into SGPRs, as the asm operands need them (inside a loop over segments -- the
+// stream-K experiment of round 4, commit 88a5214 -- hipcc reads the record with vector loads)
 __device__ __forceinline__ int w4t_uni(long v) { return __builtin_amdgcn_readfirstlane((int)v); }
 template <class T>
 __device__ __forceinline__ T* w4t_uni(T* v) {
@@ -234,32 +234,6 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   w4t_segment(ga, tile, kbeg, min(ga.K, kbeg + ga.k_split) - kbeg, ga.splits, zslice);
 }
 
-// stream-K: the launch's reduction work -- ntiles x U units of 128 k rows (U = units per tile) -- is cut into gridDim.x EQUAL contiguous
-// ranges, one per CU, instead of tiles x splits slices that leave CUs idle (108 tiles x 2 slices = 216 of 256; 196 x 1 = 196).  A
-// range spans at most a few tiles; per tile the workgroups whose ranges touch it are its parts (numbered in range order), combined in
-// the launch exactly like K slices.  ga.splits = the partial-sum slots per tile the caller allocated (>= the largest part count).
-__global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_streamk_kernel(const GroupArgs ga) {
-  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
-  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);  // XCD x owns a contiguous chunk of ranges
-  const int U = (ga.K + 127) >> 7;
-  const int total = ga.ntiles * U;  // (< 2^31: checked by the launcher)
-  const int Q = (total + W - 1) / W;
-  int u = c * Q;
-  const int end = min(u + Q, total);
-  bool first = true;
-  while (u < end) {
-    // (wave-uniform by construction; readfirstlane because the integer divisions are computed on the vector ALU)
-    const int tile = __builtin_amdgcn_readfirstlane(u / U);
-    const int k0 = u - tile * U;
-    const int len = min(U - k0, end - u);
-    const int p_first = __builtin_amdgcn_readfirstlane((tile * U) / Q), p_last = __builtin_amdgcn_readfirstlane(((tile + 1) * U - 1) / Q);
-    if (!first) __syncthreads();  // the previous segment's epilogue staging / flag word are done with
-    first = false;
-    w4t_segment(ga, tile, k0 * 128, min(ga.K - k0 * 128, len * 128), p_last - p_first + 1, c - p_first);
-    u += len;
-  }
-}
-
 // launcher used by vtp_gemm_tn_grouped (gemm8p.hip) when every problem fits this kernel (checked there: host copy of the records)
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   static bool attr_set = false;
@@ -269,35 +243,6 @@ int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   }
   hipLaunchKernelGGL(gemm4w_grouped_tn_kernel, dim3(ga.ntiles * ga.splits), dim3(256), W4T_LDS, s, ga);
   return check_launch("gemm4w_grouped_tn");
-}
-
-// number of workgroups of the stream-K launch (= CUs, a multiple of the 8 XCDs)
-int gemm4w_streamk_grid() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;  // (host-only callers: MI355X)
-    cus = prop.multiProcessorCount - prop.multiProcessorCount % 8;
-    if (cus < 8) cus = 8;
-  }
-  return cus;
-}
-
-int launch_gemm4w_grouped_tn_streamk(const GroupArgs& ga, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm4w_grouped_tn_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4T_LDS);
-    attr_set = true;
-  }
-  const long total = (long)ga.ntiles * ((ga.K + 127) / 128);
-  if (total >= (1l << 30)) {
-    set_error("gemm4w stream-K: %ld work units exceed the 32-bit range arithmetic", total);
-    return VTP_ERR_ARG;
-  }
-  const int W = gemm4w_streamk_grid();
-  hipLaunchKernelGGL(gemm4w_grouped_tn_streamk_kernel, dim3(total < W ? (int)total : W), dim3(256), W4T_LDS, s, ga);
-  return check_launch("gemm4w_grouped_tn_streamk");
 }
 
 }  // namespace vtp

@@ -720,40 +720,22 @@ int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 // ntiles * splits * 256 KiB and ntiles ints (ticket zero-initialised by the caller once; the kernel leaves it zero).
 namespace vtp {
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s);  // gemm4w_tn.hip
-int launch_gemm4w_grouped_tn_streamk(const GroupArgs& ga, hipStream_t s);
-int gemm4w_streamk_grid();
 }
 // kernel: 0 = the 8-phase kernel | 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip; the caller guarantees K % 8 == 0 and, as for
-// every grouped launch, M_g, N_g, lda, ldb multiples of 8 and operands within 32-bit byte offsets) | 2 = the same kernel as a stream-K
-// launch: one workgroup per CU, the reduction work cut into equal contiguous ranges; `splits` is then the number of partial-sum slots
-// per tile in `part` (>= vtp_gemm_tn_grouped_slots(ntiles, K))
-// partial-sum slots per tile a stream-K launch (kernel = 2) needs: the largest number of workgroup ranges that can touch one tile
-extern "C" int vtp_gemm_tn_grouped_slots(int ntiles, int K) {
-  if (ntiles < 1 || K < 1) return 0;
-  const long U = (K + 127) / 128, total = (long)ntiles * U;
-  const long W = vtp::gemm4w_streamk_grid();
-  const long Q = (total + W - 1) / W;
-  return (int)((U + Q - 2) / Q + 1);
-}
+// every grouped launch, M_g, N_g, lda, ldb multiples of 8 and operands within 32-bit byte offsets)
 extern "C" int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, int kernel,
                                      void* stream) {
   using namespace vtp;
   VTP_REQUIRE(probs && nprob >= 1 && nprob <= 8, "vtp_gemm_tn_grouped: 1..8 problems");
   VTP_REQUIRE(ntiles >= 1 && K >= 1 && splits >= 1, "vtp_gemm_tn_grouped: bad shape (ntiles %d, K %d, splits %d)", ntiles, K, splits);
   VTP_REQUIRE(splits == 1 || (part && ticket), "vtp_gemm_tn_grouped: split-K needs the partial-sum and ticket buffers");
-  VTP_REQUIRE(kernel == 0 || ((kernel == 1 || kernel == 2) && K % 8 == 0), "vtp_gemm_tn_grouped: kernel %d not available for K = %d", kernel, K);
+  VTP_REQUIRE(kernel == 0 || (kernel == 1 && K % 8 == 0), "vtp_gemm_tn_grouped: kernel %d not available for K = %d", kernel, K);
   GroupArgs ga{};
   ga.probs = (const GroupProblem*)probs; ga.part = (float*)part; ga.ticket = (int*)ticket;
   ga.nprob = nprob; ga.ntiles = ntiles; ga.K = K;
   ga.k_split = ((K + splits - 1) / splits + 63) / 64 * 64;
   ga.splits = (K + ga.k_split - 1) / ga.k_split;
   ga.timing = g_p8_timing;
-  if (kernel == 2) {
-    const int need = vtp_gemm_tn_grouped_slots(ntiles, K);
-    VTP_REQUIRE(part && ticket && splits >= need, "vtp_gemm_tn_grouped: the stream-K launch needs %d partial-sum slots per tile (got %d)", need, splits);
-    ga.splits = splits;  // slots per tile in `part`
-    return launch_gemm4w_grouped_tn_streamk(ga, (hipStream_t)stream);
-  }
   if (kernel == 1 && !ga.timing) return launch_gemm4w_grouped_tn(ga, (hipStream_t)stream);
   static bool attr_set = false;
   if (!attr_set) {

@@ -177,17 +177,14 @@ def wgrad_group_splits(ntiles: int, Ktok: int):
 def wgrad_group_kernel(ntiles: int, splits: int, Ktok: int) -> int:
     """which kernel runs a grouped weight-gradient launch: 0 = the 8-phase kernel; 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip) on the
     same tiles x slices geometry, when the token count allows its 8-row staging pieces and a K slice is long enough to amortise its
-    pipeline fill.  (2 = that kernel as a stream-K launch -- one workgroup per CU, equal contiguous ranges of the reduction work -- is
-    never chosen: measured x0.81 against the 8-phase kernel, profiles/r04_wgrad_kernel_ab.log: contiguous ranges put the workgroups of an
-    XCD on different tiles AND different k positions, nothing is shared through L2 any more and the launch becomes HBM-bound at 6 TB/s.)
-    VTP_GEMM4W_TN=0 / 1 / 2 forces the choice (same-box A/B of the step); a token count that is not a multiple of 8 always takes the
-    8-phase kernel."""
+    pipeline fill.  VTP_GEMM4W_TN=0 / 1 forces the choice (same-box A/B of the step); a token count that is not a multiple of 8
+    always takes the 8-phase kernel."""
     import os
     e = os.environ.get("VTP_GEMM4W_TN")
     if Ktok % 8 != 0 or e == "0":
         return 0
-    if e in ("1", "2"):
-        return int(e)
+    if e == "1":
+        return 1
     return 1 if Ktok // max(splits, 1) >= W4_TN_MIN_SLICE else 0
 
 
@@ -224,11 +221,9 @@ class WgradGroup:
         _, self.splits = wgrad_group_splits(self.ntiles, self.Ktok)
         self.table = torch.tensor(self.rows, dtype=torch.int64, device=device)
         self.kernel = wgrad_group_kernel(self.ntiles, self.splits, self.Ktok)
-        # partial-sum slots per tile: the K slices of the fixed geometry, or the most workgroup ranges a stream-K launch lets touch a tile
-        self.slots = max(self.splits, _lib_().vtp_gemm_tn_grouped_slots(self.ntiles, self.Ktok) if self.Ktok % 8 == 0 else 0)
-        if self.slots > 1:
+        if self.splits > 1:
             scratch = {} if scratch is None else scratch
-            need = self.ntiles * self.slots * 65536
+            need = self.ntiles * self.splits * 65536
             if scratch.get("part") is None or scratch["part"].numel() < need:
                 scratch["part"] = torch.empty(need, dtype=torch.float32, device=device)
             if scratch.get("ticket") is None or scratch["ticket"].numel() < self.ntiles:
@@ -237,12 +232,12 @@ class WgradGroup:
         return self
 
     def launch(self, kernel=None):
-        """kernel: 0 = the 8-phase kernel, 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip), 2 = that kernel as a stream-K launch, None = the
-        measured choice made by finalize() (ops.wgrad_group_kernel)"""
+        """kernel: 0 = the 8-phase kernel, 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip), None = the measured choice made by finalize()
+        (ops.wgrad_group_kernel)"""
         if kernel is None:
             kernel = self.kernel
-        _lib.check(_lib_().vtp_gemm_tn_grouped_k(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.slots if kernel == 2 else self.splits,
-                                                  _p(self.part), _p(self.ticket), kernel, _s()), "vtp_gemm_tn_grouped")
+        _lib.check(_lib_().vtp_gemm_tn_grouped_k(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.splits, _p(self.part),
+                                                  _p(self.ticket), kernel, _s()), "vtp_gemm_tn_grouped")
 
 
 def colsum_bf16(inp, ld, out, R, C, swiglu_h=0, in_remap=(0, 0)):
