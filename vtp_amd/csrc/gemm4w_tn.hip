@@ -10,7 +10,8 @@
 //     rows of 128 B) twice each.  (XOR 4 (k & 1) left half the banks idle: 49 % of the LDS cycles were conflict cycles.)
 //   * wave w stages A sub-image w (in the Y step) and B sub-image w (in the X step): 8 LDS-DMA pieces of 8 k rows each; pieces whose k
 //     rows lie beyond the slice read a zero block (so a slice needs no K-tail path, and an odd k-tile count is padded with a zero one);
-//   * ring of two k-tiles (128 KiB) + 32 KiB: publish flag of the combine; 160 KiB, one workgroup per CU.
+//   * ring of two k-tiles (128 KiB) + 32 KiB (4 KiB per wave of fp32 epilogue staging; the arrival flag of the combine in its last
+//     word): 160 KiB, one workgroup per CU.
 // Limits (launcher; otherwise the 8-phase kernel takes the launch): M, N, K multiples of 8, 32-bit operand offsets.
 #include "gemm_common.h"
 #include "gemm_group.h"
