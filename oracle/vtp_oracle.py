@@ -396,7 +396,7 @@ def ssl_loss(t_out, s_out, masks, center_dino, center_ibot, n_local: int, studen
     if centering == "sinkhorn_knopp":
         p_cls = sinkhorn_knopp(tc.float(), teacher_temp, sk_iterations).float()
     else:
-        p_cls = F.softmax((tc - center_dino) / teacher_temp, dim=-1)
+        p_cls = F.softmax((tc - center_dino.to(tc.device)) / teacher_temp, dim=-1)
     lsm_g = F.log_softmax(s_out["student_global_cls_tokens_after_head"] / student_temp, dim=-1)
     lsm_l = F.log_softmax(s_out["student_local_cls_tokens_after_head"] / student_temp, dim=-1)
     terms = 2 * 1 + n_local * 2
@@ -405,13 +405,14 @@ def ssl_loss(t_out, s_out, masks, center_dino, center_ibot, n_local: int, studen
     for v in range(2):
         dino = dino - (p_cls[v * B:(v + 1) * B][None] * lsm_l).sum(-1).sum() / B
     dino = dino / terms
-    ibot = torch.zeros(())
+    ibot = tc.new_zeros(())  # (device-agnostic: the benchmarked-geometry parity test evaluates this oracle on the GPU in fp32)
     if tp.shape[0] > 0:
         if centering == "sinkhorn_knopp":
             p_pat = sinkhorn_knopp(tp.float(), teacher_temp, sk_iterations).float()
         else:
-            p_pat = F.softmax((tp - center_ibot) / teacher_temp, dim=-1)
+            p_pat = F.softmax((tp - center_ibot.to(tp.device)) / teacher_temp, dim=-1)
         lsm_p = F.log_softmax(s_out["student_global_masked_patch_tokens_after_head"] / student_temp, dim=-1)
+        masks = masks.to(tp.device)
         per_img = masks.sum(1).clamp(min=1)
         img_of = masks.nonzero()[:, 0]
         w = 1.0 / per_img[img_of].float()

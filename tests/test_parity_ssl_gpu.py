@@ -157,19 +157,21 @@ SMALL = 4096  # elements: below this a gradient tensor (bias, norm gain, token, 
 
 
 def _compare_grads(tag, params, keys, G):
-    """per-tensor rule E_ours <= 1.25 E_ref for the sampled tensors with >= SMALL elements; tensors below that (biases, gains, tokens)
-    are pooled -- their own relF is dominated by a handful of elements (the five largest carry 16-29 % of the squared error of the
-    256-element dino_head.mlp.4.bias; its ratio came out 1.46 with one seed and 0.65 with the next, tools/diag_parity_bias.py,
-    profiles/r04_parity.log): the POOLED small tensors must meet 1.25, each single one 2.0 (the slack of the other single-draw
-    statistics); a ONE-element gradient takes visual_proj.weight's E_ref as its floor (see `check`).  All tensors flat: 1.25."""
+    """per-tensor rule E_ours <= 1.25 E_ref for the sampled tensors with >= SMALL elements.  Tensors below that (biases, gains, tokens)
+    are POOLED here (bar 1.25 on the pool) and only reported one by one: their own single-run relF is dominated by a handful of elements
+    (the five largest carry 16-29 % of the squared error of the 256-element dino_head.mlp.4.bias; its ratio came out 1.46 with one seed
+    and 0.65 with the next, tools/diag_parity_bias.py).  Their PER-TENSOR statement is made where it can be made soundly:
+    tests/test_parity_bench_gpu.py::test_small_tensor_ratios_multi_seed -- mean ratio over 5 input seeds <= 1.25 for every one of them
+    (round 5; the "2.0 each" single-draw cap of round 4 is gone).  A ONE-element gradient takes visual_proj.weight's E_ref as its floor
+    (see `check`).  All tensors flat: 1.25."""
     worst, worst_k = 0.0, None
     vp = "visual_proj.weight"
     floor = max(relF(G["cpu16"][vp], G["f32"][vp]), relF(G["gpu16"][vp], G["f32"][vp])) if vp in G["f32"] else 0.0
     pool = [0.0, 0.0, 0.0, 0.0, 0]  # sum of squared errors: ours, cpu16, gpu16; squared reference norm; tensors
     for k in keys:
         n = G["f32"][k].numel()
-        r = check(f"{tag} grad {k}", params[k].grad, G["f32"][k], G["cpu16"][k], G["gpu16"][k], slack=1.25 if n >= SMALL else 2.0,
-                  e_ref_min=floor if n == 1 else 0.0)
+        r = check(f"{tag} grad {k}", params[k].grad, G["f32"][k], G["cpu16"][k], G["gpu16"][k],
+                  slack=1.25 if (n >= SMALL or n == 1) else float("inf"), e_ref_min=floor if n == 1 else 0.0)
         if 1 < n < SMALL:
             g = G["f32"][k]
             pool[0] += float((params[k].grad.float().cpu() - g).pow(2).sum())
