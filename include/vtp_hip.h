@@ -159,7 +159,6 @@ int vtp_im2col16(const float* img, void* patches, int B, int H, int W, void* str
 /* gradient w.r.t. the input image of PatchEmbed (embeddings.py:61-70 backward; the reference's autograd returns it when the image
  * requires grad): d_patches f32 [B*hw, 768] (= d_tokens[patch rows] W_pe, K order (c, ky, kx)) folded back to d_img f32 [B,3,H,W] */
 int vtp_col2im16(const float* dpatches, float* dimg, int B, int H, int W, void* stream);
-/* col2im adjoint is not needed: the image is data (no input gradient). */
 
 /* rows [B, N, D] f32: write row 0 of every batch element = cls[D] (vision_transformer.py:198,210-217);
  * optionally substitute mask_token on masked patch rows (vision_transformer.py:195). masks: uint8 [B, N-1] or NULL. */
@@ -194,6 +193,10 @@ int vtp_cast_transpose_f32_bf16(const float* in, void* out, int R, int C, void* 
  * src2=w2 (16-row groups = [8 rows w1 | 8 rows w2], R = 2H); mode 2: dst f32 [R] = interleave of two bias vectors.
  * tile_start = exclusive prefix sum of per-record tile counts (64x64 tiles; mode 2: 256 elements per tile). */
 int vtp_prep_weights(const void* descs, int n, int total_tiles, void* stream);
+/* the same over a RUN of the table (the layers of one gradient bucket, refreshed right behind that bucket's optimizer update while the
+ * backward of the other layers is still running): descs = the run's first record, n records, tile_base = that record's tile_start,
+ * n_tiles = tiles of the run. */
+int vtp_prep_weights_range(const void* descs, int n, int tile_base, int n_tiles, void* stream);
 
 /* SwiGLU backward (ffn.py:80): given dh bf16 [M,H] and saved x12 bf16 [M,2H] (interleaved 8|8), writes dx12 bf16 [M,2H].
  * db12 (optional, f32 [2H] = [b1 | b2], accumulated): column sums of dx12 = the bias gradients of w1 / w2. */
@@ -230,6 +233,11 @@ int vtp_reduce_slabs(const float* slabs, long stride, int S, float* dst, long n,
 /* EMA teacher update t = m*t + (1-m)*s over a flat buffer (vtp.py:388-401). */
 int vtp_ema(float* t, const float* s, long n, float momentum, void* stream);
 int vtp_ema_dev(float* t, const float* s, long n, const float* momentum /* device scalar */, void* stream);
+/* AdamW (vtp_adamw_dev_masked; nodecay4 may be NULL) with the EMA update of the teacher's copy of the same elements fused in
+ * (teacher = mom * teacher + (1 - mom) * p_new, vtp.py:388-401; teacher may be NULL; mom = hyper[9]): ONE pass over a gradient
+ * bucket for the per-bucket optimizer lane of the training step.  Short-lived blocks (4096 elements each). */
+int vtp_adamw_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, const void* nodecay4, long n, const float* hyper,
+                      void* stream);
 
 /* ---- CLIP text-tower glue + contrastive head (fp32; clip.hip) -------------------------------------------------
  * embed: x f32 [B*T, D] = table[ids] + pos (modeling_vtp.py:296-297); eot[b] = argmax_t ids[b,t] (text_global_pool

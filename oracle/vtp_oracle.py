@@ -276,7 +276,10 @@ def text_block(x: Tensor, sd, pre: str, num_heads: int, causal: bool = True, qui
 def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True, pool_type: str = "argmax",
                       causal: bool = True, quick_gelu: bool = False) -> Tensor:
     """VTPModel.get_clip_text_feature -- modeling_vtp.py:278-310; text_global_pool text_transformer.py:213-228 (argmax = EOT | first
-    | last); causal = not text_no_causal_mask (text_transformer.py:285-288)."""
+    | last | none = every token, result [B, T, D]); causal = not text_no_causal_mask (text_transformer.py:285-288).
+    text_embed_cls (text_transformer.py:268-272): the class keeps TextTransformer's positional_embedding [context_length + 1, D] and
+    its (context_length + 1)^2 causal mask but NOT cls_emb / build_cls_mask (modeling_vtp.py:163-170 re-hangs the parts and never
+    calls TextTransformer._embeds), so `text` must simply carry context_length + 1 ids -- nothing else changes here."""
     x = F.embedding(text, sd["token_embedding.weight"]) + sd["positional_embedding"]
     for i in range(_depth(sd, "text_transformer.resblocks.")):
         x = text_block(x, sd, f"text_transformer.resblocks.{i}.", num_heads, causal=causal, quick_gelu=quick_gelu)
@@ -285,7 +288,7 @@ def clip_text_feature(sd, text: Tensor, num_heads: int, normalize: bool = True, 
         x = x[:, 0]
     elif pool_type == "last":
         x = x[:, -1]
-    else:
+    elif pool_type == "argmax":
         x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
     x = x @ sd["text_projection"]
     return F.normalize(x, dim=-1) if normalize else x

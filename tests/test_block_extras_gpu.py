@@ -51,11 +51,12 @@ def test_block_extra_kernels_vs_torch():
     assert torch.equal(wt, (W * gamma[:, None]).T.to(torch.bfloat16))
 
 
-def _model(init_values):
+def _model(init_values, **extra):
     from oracle.ref_stubs import TINY
     from vtp_amd import VTPConfig, VTPModel
     cfg = dict(TINY)
     cfg.update(vision_depth=3, decoder_depth=2, vision_init_values=init_values, decoder_init_values=init_values and 0.6 * init_values)
+    cfg.update(extra)
     torch.manual_seed(8)
     m = VTPModel(VTPConfig(**cfg))
     with torch.no_grad():
@@ -157,6 +158,50 @@ def test_stochastic_depth_step_vs_oracle(init_values):
         t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=9, use_graphs=use_graphs)
         res.append([float(t2.step_rec(img.to(DEV) + 0.01 * i)) for i in range(3)])
     print("drop eager:", res[0], "graphs:", res[1])
+    for a, b in zip(*res):
+        assert abs(a - b) < 2e-3 * abs(a)
+
+
+def test_stochastic_depth_with_mlp_ffn_vs_oracle():
+    """ffn_layer = "mlp" (fc1 -> GELU -> fc2, ffn.py:21-48) under stochastic depth (block.py:207-289), trunk AND decoder -- the
+    combination round 4 rejected at set_drop_plan time: same protocol as the SwiGLU test above"""
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPTrainer
+    m, sd = _model(None, vision_ffn_layer="mlp", decoder_ffn_layer="mlp")
+    assert "trunk.blocks.0.mlp.fc1.weight" in sd and "pixel_decoder.blocks.1.mlp.fc2.bias" in sd
+    B = 5
+    img = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=5)
+    loss = tr.step_rec(img.to(DEV))
+    torch.cuda.synchronize()
+
+    def plan_of(stack):
+        p = stack.last_drop_plan
+        keep, alpha = p["keeps"][0], p["scales"][0]
+        idx = p["idx_dev"].cpu().long().view(stack.depth, 2, keep)
+        return [(idx[i, 0], alpha, idx[i, 1], alpha) for i in range(stack.depth)]
+
+    d_tr, d_dec = plan_of(tr.trunk.stack), plan_of(tr.decoder.stack)
+    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    out = O.trunk_forward(ref, img, 2, use_bottleneck=True, drop=d_tr)
+    loss_ref = O.l1_loss(O.decoder_forward(ref, out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, drop=d_dec), img)
+    loss_ref.backward()
+    ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o16 = O.trunk_forward(ref16, img, 2, use_bottleneck=True, drop=d_tr)
+        l16 = O.l1_loss(O.decoder_forward(ref16, o16["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, drop=d_dec), img)
+    l16.backward()
+    print(f"stochastic depth with the Mlp FFN: loss ours {float(loss):.5f} oracle {float(loss_ref):.5f}")
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+    _compare_grads(m, ref, ["trunk.blocks.0.mlp.fc1.weight", "trunk.blocks.1.mlp.fc1.bias", "trunk.blocks.2.mlp.fc2.weight",
+                            "trunk.blocks.1.mlp.fc2.bias", "trunk.blocks.0.attn.qkv.weight", "trunk.blocks.2.norm2.weight",
+                            "pixel_decoder.blocks.0.mlp.fc1.weight", "pixel_decoder.blocks.1.mlp.fc2.bias", "pixel_decoder.proj_in.weight",
+                            "trunk.patch_embed.proj.weight"], 3e-2, ref16)
+    res = []
+    for use_graphs in (False, True):
+        m2, _ = _model(None, vision_ffn_layer="mlp", decoder_ffn_layer="mlp")
+        t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=9, use_graphs=use_graphs)
+        res.append([float(t2.step_rec(img.to(DEV) + 0.01 * i)) for i in range(3)])
     for a, b in zip(*res):
         assert abs(a - b) < 2e-3 * abs(a)
 

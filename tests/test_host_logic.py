@@ -75,6 +75,47 @@ def test_range_helpers():
     assert param_ranges(offs, ("trunk.", "pixel_decoder.")) == [(0, 8), (12, 20)]
 
 
+def test_optimizer_lane_pieces_and_table_runs():
+    """per-bucket optimizer lane (vtp_amd/train.py): a bucket's flat ranges are cut at the borders of the EMA-tracked groups, each piece
+    carries the offset of the teacher's copy; ParamStore.desc_runs picks the weight-refresh records whose sources lie in given ranges"""
+    from vtp_amd.train import lane_pieces
+    # student groups: trunk [0, 100) -> teacher at 1000; head [200, 260) -> teacher at 1100
+    pairs = [(1000, 0, 100), (1100, 200, 260)]
+    assert lane_pieces([(40, 60)], pairs) == [(40, 60, 1040)]
+    assert lane_pieces([(80, 120)], pairs) == [(80, 100, 1080), (100, 120, None)]       # leaves the trunk group
+    assert lane_pieces([(150, 300)], pairs) == [(150, 200, None), (200, 260, 1100), (260, 300, None)]
+    assert lane_pieces([(0, 100), (200, 260)], []) == [(0, 100, None), (200, 260, None)]  # no teacher: plain AdamW
+    covered = lane_pieces([(0, 300)], pairs)
+    assert [a for a, _, _ in covered] == [0, 100, 200, 260] and covered[-1][1] == 300
+    from vtp_amd.engine import ParamStore
+    st = ParamStore.__new__(ParamStore)
+    st._desc_src = [0, 16, 48, 64, 200, 232, 1000, 1016]
+    assert st.desc_runs([(0, 50)]) == [(0, 3)]
+    assert st.desc_runs([(16, 17), (200, 260)]) == [(1, 2), (4, 6)]
+    assert st.desc_runs([(40, 48)]) == []
+    assert st.desc_runs([(0, 50)]) + st.desc_runs([(1000, 1050)]) == [(0, 3), (6, 8)]
+
+
+def test_bucket_waits_can_be_partial():
+    """GradBucketer.wait(works) takes in a given list (the previous bucket event's reductions) and leaves the rest outstanding"""
+    from vtp_amd.train import GradBucketer
+
+    class W:
+        def __init__(self):
+            self.done = 0
+
+        def wait(self):
+            self.done += 1
+    gb = GradBucketer.__new__(GradBucketer)
+    a, b = W(), W()
+    hit = []
+    gb.works = [(b, None)]
+    gb.wait([(a, lambda: hit.append(1))])
+    assert a.done == 1 and b.done == 0 and hit == [1] and len(gb.works) == 1
+    gb.wait()
+    assert b.done == 1 and gb.works == []
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

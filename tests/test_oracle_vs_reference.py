@@ -281,6 +281,40 @@ def test_text_pooling_and_mask_variants_match_reference(pool, no_causal, ls, qui
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("embed_cls,pool", [(True, "argmax"), (True, "last"), (False, "none"), (True, "none")])
+def test_text_embed_cls_and_pool_none_match_reference(embed_cls, pool):
+    """text_embed_cls and text_pool_type = "none" AT THE CLASS BOUNDARY (round 5).  What the reference class does with them
+    (modeling_vtp.py:142-170,296-310): it re-hangs TextTransformer's parts, so embed_cls leaves a positional table / causal mask of
+    context_length + 1 positions but NO cls_emb and no padding mask (text_transformer.py:340-357 is never reached) -- captions must then
+    carry context_length + 1 ids (the stock length fails in `x + positional_embedding`); pool "none" returns every token's projected,
+    normalised feature [B, T, D] and get_clip_logits fails in its matmul.  Pinned here: state_dict keys / shapes of ours, the oracle
+    against the real class, and the error cases."""
+    from oracle.ref_stubs import TINY, load_reference
+    from vtp_amd import VTPConfig, VTPModel
+    ref = load_reference()
+    torch.manual_seed(6)
+    kw = dict(TINY, text_embed_cls=embed_cls, text_pool_type=pool)
+    m = ref.VTPModel(ref.VTPConfig(**kw)).eval()
+    sd = m.state_dict()
+    ours = VTPModel(VTPConfig(**kw))
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    L = TINY["text_context_length"]
+    T = L + 1 if embed_cls else L
+    assert ours.config.text_num_pos == T == sd["positional_embedding"].shape[0] and not any("cls_emb" in k for k in sd)
+    text = torch.randint(1, 500, (3, T))
+    text[:, 9] = 511
+    with torch.no_grad():
+        want = m.get_clip_text_feature(text)
+        got = O.clip_text_feature(sd, text, 2, pool_type=pool)
+    assert want.shape == ((3, T, TINY["text_embed_dim"]) if pool == "none" else (3, TINY["text_embed_dim"]))
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    with pytest.raises(RuntimeError):  # the other caption length does not fit the positional table
+        m.get_clip_text_feature(torch.randint(1, 500, (3, L if embed_cls else L + 1)))
+    if pool == "none":
+        with pytest.raises(RuntimeError):
+            m.get_clip_logits(torch.randn(3, 3, 64, 64), text)
+
+
 @pytest.mark.parametrize("vis,dec", [("mlp", "mlp"), ("swiglu64", "swiglu")])
 def test_ffn_layer_variants_match_reference(vis, dec):
     """ffn_layer = "mlp" (GELU Mlp, ffn.py:21-48) and the aligned SwiGLU widths (vision_transformer.py:22-28): parameter names /

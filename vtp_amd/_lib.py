@@ -26,6 +26,7 @@ SIGNATURES = {
     "vtp_cast_f32_bf16": [_P, _P, _L, _P],
     "vtp_cast_transpose_f32_bf16": [_P, _P, _I, _I, _P],
     "vtp_prep_weights": [_P, _I, _I, _P],
+    "vtp_prep_weights_range": [_P, _I, _I, _I, _P],
     "vtp_swiglu_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "vtp_gemm_dgrad_swiglu": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "vtp_gelu_bwd": [_P, _P, _P, _L, _P],
@@ -79,6 +80,7 @@ SIGNATURES = {
     "vtp_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vtp_lpips_tap": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "vtp_ema_dev": [_P, _P, _L, _P, _P],
+    "vtp_adamw_ema_dev": [_P, _P, _P, _P, _P, _P, _L, _P, _P],
     "vtp_embed_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_embed_tokens_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_gather_rows": [_P, _P, _P, _I, _I, _I, _P],

@@ -102,7 +102,7 @@ class TrunkTokens(torch.autograd.Function):
         d_xnf.copy_(d_tokens.reshape(d_xnf.shape))  # f32 -> bf16, every row written
         want = ctx.needs_input_grad[0]  # the image itself requires grad (the reference's autograd would deliver d/d image)
         _drain(tr.backward(None, ctx=ctx.tctx, want_dimg=want))
-        return (ctx.tctx.d_img[0].to(ctx.img_dtype) if want else None), None, None, None
+        return (ctx.tctx.take_d_img(0).to(ctx.img_dtype) if want else None), None, None, None
 
 
 class EncodeLatents(torch.autograd.Function):
@@ -134,7 +134,7 @@ class EncodeLatents(torch.autograd.Function):
         d_xnf.zero_()  # the bottleneck dgrad writes the patch rows only: the cls rows carry no gradient on this path
         want = ctx.needs_input_grad[0]
         _drain(tr.backward(d_tok, ctx=ctx.tctx, want_dimg=want))
-        return (ctx.tctx.d_img[0].to(ctx.img_dtype) if want else None), None, None, None
+        return (ctx.tctx.take_d_img(0).to(ctx.img_dtype) if want else None), None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------- pixel decoder

@@ -17,7 +17,7 @@ I32 = torch.int32
 class TextEngine:
     def __init__(self, store: ParamStore, cfg):
         self.store = store
-        self.D, self.heads, self.depth, self.T = cfg.text_embed_dim, cfg.text_num_heads, cfg.text_depth, cfg.text_context_length
+        self.D, self.heads, self.depth, self.T = cfg.text_embed_dim, cfg.text_num_heads, cfg.text_depth, cfg.text_num_pos
         self.H = int(self.D * cfg.text_mlp_ratio)
         self.Dout = cfg.text_embed_dim  # output_dim = text_embed_dim (modeling_vtp.py:150)
         self.stack = Stack(store, "text_transformer.resblocks.", self.depth, self.D, self.heads, self.H, "layernorm",
@@ -38,7 +38,8 @@ class TextEngine:
         return self.ws[B]
 
     def forward(self, ids: torch.Tensor, train: bool) -> torch.Tensor:
-        """ids int64 [B, T] (device) -> un-normalised text features f32 [B, Dout]  (modeling_vtp.py:278-310)."""
+        """ids int64 [B, T] (device) -> un-normalised text features f32 [B, Dout]  (modeling_vtp.py:278-310); text_pool_type = "none"
+        (text_global_pool's fall-through, text_transformer.py:225-226): every token, f32 [B * T, Dout]."""
         st = self.store
         B, T = ids.shape
         D = self.D
@@ -46,9 +47,17 @@ class TextEngine:
         x0 = ws.get("x0", (B * T, D), F32)
         eot = ws.get("eot", (B,), I32)
         ops.embed_tokens(ids, st.p("token_embedding.weight"), st.p("positional_embedding"), x0, eot, B, T, D)
-        if self.pool != "argmax":  # the kernel wrote the arg-max position of every row; 'first' / 'last' pool a fixed position
+        if self.pool in ("first", "last"):  # the kernel wrote the arg-max position of every row; 'first' / 'last' pool a fixed position
             eot.fill_(0 if self.pool == "first" else T - 1)
         xl = self.stack.forward(ws, x0, B, T, None, 0, train)
+        if self.pool == "none":  # ln_final and the projection over all B * T rows
+            xn = ws.get("all_n", (B * T, D), BF)
+            stf = ws.get("all_stf", (B * T, 2), F32)
+            ops.norm_fwd(xl, st.p("ln_final.weight"), st.p("ln_final.bias"), xn, stf, B * T, D, 1e-5, ops.NORM_LN)
+            feat = ws.get("all_feat", (B * T, self.Dout), F32)
+            ops.gemm_nt(xn, self.proj.wT, feat, M=B * T, N=self.Dout, K=D, epi=EPI_F32)
+            self._ctx = (ws, ids, B, T, None, xl, xn, stf)
+            return feat
         pooled = ws.get("pooled", (B, D), F32)
         ops.gather_rows(xl, eot, pooled, B, T, D)  # ln_final is row-wise: pool first, normalise B rows instead of B*T
         pn = ws.get("pooled_n", (B, D), BF)
@@ -65,6 +74,23 @@ class TextEngine:
         st = self.store
         ws, ids, B, T, eot, pooled, pn, stf = self._ctx
         D = self.D
+        if eot is None:  # text_pool_type = "none": the same head over all B * T rows, no pooling scatter
+            R = B * T
+            d_feat_b = ws.get("b.all_d_feat_b", (R, self.Dout), BF)
+            ops.cast_f32_bf16(d_feat, d_feat_b, R * self.Dout)
+            linear_bwd(ws, "tproj", None, pn, d_feat_b, R, None, need_dx=False, N=D, K=self.Dout, gw=self.proj.gw, gb=None, wT=None)
+            d_pn = ws.get("b.all_d_pn", (R, D), BF)
+            ops.gemm_nt(d_feat_b, self.proj.w, d_pn, M=R, N=D, K=self.Dout, epi=EPI_BF16)
+            dx = ws.get("b.dxt", (R, D), F32)
+            dx_b = ws.get("b.dxt_b", (R, D), BF)
+            ops.norm_bwd(d_pn, pooled, st.p("ln_final.weight"), stf, None, dx, dx_b, st.g("ln_final.weight"), st.g("ln_final.bias"), R, D,
+                         ops.NORM_LN)
+            OVERLAP.join()
+            yield "tail"
+            dx0, _ = yield from self.stack.backward(ws, dx, dx_b, B, T, None, 0)
+            ops.embed_tokens_bwd(ids, dx0, st.g("token_embedding.weight"), st.g("positional_embedding"), B, T, D)
+            OVERLAP.join()
+            return
         d_feat_b = ws.get("b.d_feat_b", (B, self.Dout), BF)
         ops.cast_f32_bf16(d_feat, d_feat_b, B * self.Dout)
         # dP [D, Dout] += pn^T d_feat  (roles of "dy" and "x" swapped so the result lands in the parameter's layout)

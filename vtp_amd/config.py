@@ -77,10 +77,15 @@ class VTPConfig:
         need(self.vision_norm_layer in ("rmsnorm", "layernorm"), "vision_norm_layer must be rmsnorm|layernorm")
         need(self.decoder_norm_layer in ("rmsnorm", "layernorm"), "decoder_norm_layer must be rmsnorm|layernorm")
         need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
-        need(not self.text_embed_cls, "text tower: embed_cls (an appended class embedding with its padding mask) is not implemented")
-        need(self.text_pool_type in ("argmax", "first", "last"),
-             "text_pool_type must be argmax | first | last ('none' returns per-token features: not implemented)")
+        need(self.text_pool_type in ("argmax", "first", "last", "none"), "text_pool_type must be argmax | first | last | none")
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
+
+    @property
+    def text_num_pos(self) -> int:
+        """rows of positional_embedding = tokens get_clip_text_feature expects: context_length, + 1 with text_embed_cls -- the
+        reference class keeps TextTransformer's enlarged positional table and causal mask (text_transformer.py:268-272) but neither
+        cls_emb nor the padding mask of build_cls_mask (modeling_vtp.py:163-170), so the extra position is an ordinary token"""
+        return int(self.text_context_length) + (1 if self.text_embed_cls else 0)
 
     def to_dict(self):
         d = {k: v for k, v in self.__dict__.items() if k != "extra"}

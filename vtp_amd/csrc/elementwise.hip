@@ -276,15 +276,18 @@ struct PrepDesc {
   long tile_start;
 };
 
-__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepDesc* __restrict__ descs, int n) {
+__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepDesc* __restrict__ descs, int n, int tile_base) {
   __shared__ float tile[64][65];
+  // tile_base: a launch over a RUN of the descriptor table (vtp_prep_weights_range: the layers of one gradient bucket) passes the
+  // run's first descriptor and the absolute index of its first tile
+  const long tile_id = (long)blockIdx.x + tile_base;
   int lo = 0, hi = n - 1;
-  while (lo < hi) {  // last descriptor with tile_start <= blockIdx.x
+  while (lo < hi) {  // last descriptor with tile_start <= tile_id
     const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].tile_start <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (descs[mid].tile_start <= tile_id) lo = mid; else hi = mid - 1;
   }
   const PrepDesc d = descs[lo];
-  const int t = (int)(blockIdx.x - d.tile_start);
+  const int t = (int)(tile_id - d.tile_start);
   const int R = (int)d.R, C = (int)d.C;
   if (d.mode == 2) {  // bias interleave, 1-D: 256 elements per tile
     const int g = t * 256 + threadIdx.x;
@@ -490,6 +493,53 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const f
   }
 }
 
+// AdamW of one gradient bucket with the EMA-teacher update of the same elements fused in (vtp.py:388-401: t = mom t + (1 - mom) s on
+// the freshly updated student), for the optimizer lane of the training step (vtp_amd/train.py): launched on a side stream as soon as a
+// bucket's gradients are final, it runs beside the rest of the backward -- so a block is SHORT-LIVED (4096 elements, no grid-stride
+// loop: it takes a free CU slot between the persistent GEMM workgroups and gives it back after one round of loads and stores) and
+// requests all of its 16-20 float4 loads before the first use.  hyper[9] = teacher momentum.  Same arithmetic, element by element,
+// as adamw_kernel followed by ema_kernel.
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ t, long n4,
+                                                        const float* __restrict__ hyper, const uint8_t* __restrict__ nodecay4) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2_sqrt = hyper[6], gs = hyper[7];
+  const float mom = hyper[9];
+  const long base = blockIdx.x * 1024L + threadIdx.x;
+  f32x4 pv[4], gv[4], mv[4], vv[4], tv[4];
+  bool nd[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = base + u * 256;
+    if (i < n4) {
+      pv[u] = *(const f32x4*)(p + 4 * i);
+      gv[u] = *(const f32x4*)(g + 4 * i);
+      mv[u] = *(const f32x4*)(m + 4 * i);
+      vv[u] = *(const f32x4*)(v + 4 * i);
+      if (t) tv[u] = *(const f32x4*)(t + 4 * i);
+      nd[u] = nodecay4 && nodecay4[i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = base + u * 256;
+    if (i >= n4) continue;
+    const float keep = nd[u] ? 1.f : 1.f - lr * wd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = gv[u][e] * gs;
+      pv[u][e] *= keep;
+      mv[u][e] = b1 * mv[u][e] + (1.f - b1) * gg;
+      vv[u][e] = b2 * vv[u][e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
+      pv[u][e] -= (lr / bc1) * (mv[u][e] / denom);
+    }
+    *(f32x4*)(p + 4 * i) = pv[u];
+    *(f32x4*)(m + 4 * i) = mv[u];
+    *(f32x4*)(v + 4 * i) = vv[u];
+    if (t) *(f32x4*)(t + 4 * i) = tv[u] * mom + pv[u] * (1.f - mom);
+  }
+}
+
 // out[d] += sum_b in[b*stride + d]   (cls-token gradient: rows b*N of the [B,N,D] stream)
 __global__ __launch_bounds__(256) void strided_rowsum_kernel(const float* __restrict__ in, long stride, float* __restrict__ out, int B, int D) {
   const int d = blockIdx.x * 256 + threadIdx.x;
@@ -631,8 +681,14 @@ extern "C" int vtp_cast_transpose_f32_bf16(const float* in, void* out, int R, in
 
 extern "C" int vtp_prep_weights(const void* descs, int n, int total_tiles, void* stream) {
   VTP_REQUIRE(descs && n > 0 && total_tiles > 0, "vtp_prep_weights: bad argument");
-  hipLaunchKernelGGL(prep_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const PrepDesc*)descs, n);
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const PrepDesc*)descs, n, 0);
   return check_launch("prep_weights");
+}
+
+extern "C" int vtp_prep_weights_range(const void* descs, int n, int tile_base, int n_tiles, void* stream) {
+  VTP_REQUIRE(descs && n > 0 && tile_base >= 0 && n_tiles > 0, "vtp_prep_weights_range: bad argument");
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, (const PrepDesc*)descs, n, tile_base);
+  return check_launch("prep_weights_range");
 }
 
 extern "C" int vtp_swiglu_bwd(const void* dh, const void* x12, void* dx12, float* db12, int M, int H, void* stream) {
@@ -726,4 +782,13 @@ extern "C" int vtp_ema_dev(float* t, const float* s, long n, const float* moment
   VTP_REQUIRE(t && s && momentum && n > 0 && n % 4 == 0, "vtp_ema_dev: bad argument (n %% 4 == 0)");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, t, s, n, 0.f, momentum);
   return check_launch("ema_dev");
+}
+
+extern "C" int vtp_adamw_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, const void* nodecay4, long n,
+                                 const float* hyper, void* stream) {
+  VTP_REQUIRE(p && g && m && v && hyper && n > 0 && n % 4 == 0, "vtp_adamw_ema_dev: bad argument (n %% 4 == 0)");
+  VTP_REQUIRE(n / 4096 < 0x7fffffffL, "vtp_adamw_ema_dev: range too long for one launch");
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, teacher,
+                     n / 4, hyper, (const uint8_t*)nodecay4);
+  return check_launch("adamw_ema_dev");
 }

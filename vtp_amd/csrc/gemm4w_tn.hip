@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   w4t_segment(ga, tile, kbeg, min(ga.K, kbeg + ga.k_split) - kbeg, ga.splits, zslice);
 }
 
-// launcher used by vtp_gemm_tn_grouped (gemm8p.hip) when every problem fits this kernel (checked there: host copy of the records)
+// launcher used by vtp_gemm_tn_grouped_k (gemm8p.hip, kernel = 1).  The problem records live in DEVICE memory, so the C entry can only
+// check what it is passed by value (token count % 8); the per-problem limits of this kernel -- M_g, N_g and both leading dimensions
+// multiples of 8 (16-B staging pieces, `min(.., M - 8)` column clamps), operand spans below 4 GiB (32-bit lane offsets) -- are enforced
+// where the records are BUILT: ops.WgradGroup.add / finalize raise ValueError (vtp_amd/ops.py), and a C caller must do the same.
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {

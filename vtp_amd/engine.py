@@ -141,33 +141,58 @@ class ParamStore:
             n = shape[0] * shape[1]
             setattr(obj, attr, self.flat_bf16[off:off + n].view(shape))
         rows, tiles = [], 0
+        self._desc_src = []  # flat-buffer offset of each record's (first) fp32 source: which gradient bucket refreshes it (desc_runs)
 
-        def add(src, src2, dst, dstT, R, C, mode):
+        def add(src, src2, dst, dstT, R, C, mode, name):
             nonlocal tiles
             rows.append([src, src2, dst, dstT, R, C, mode, tiles])
+            self._desc_src.append(self.offsets[name][0])
             tiles += (R + 255) // 256 if mode == 2 else ((R + 63) // 64) * ((C + 63) // 64)
 
         for d in self._descs:
             if d[0] == "lin":
                 _, L, wname, need_T = d
-                add(self.p(wname).data_ptr(), 0, L.w.data_ptr(), L.wT.data_ptr() if need_T else 0, L.N, L.K, 0)
+                add(self.p(wname).data_ptr(), 0, L.w.data_ptr(), L.wT.data_ptr() if need_T else 0, L.N, L.K, 0, wname)
             else:
                 _, S, prefix = d
                 b12 = torch.zeros(2 * S.H, dtype=torch.float32, device=self.device)
                 S.b12 = b12
                 self._keep.append(b12)
                 add(self.p(prefix + "w1.weight").data_ptr(), self.p(prefix + "w2.weight").data_ptr(), S.w12.data_ptr(),
-                    S.w12T.data_ptr(), 2 * S.H, S.K, 1)
+                    S.w12T.data_ptr(), 2 * S.H, S.K, 1, prefix + "w1.weight")
                 add(self.p(prefix + "w1.bias").data_ptr(), self.p(prefix + "w2.bias").data_ptr(), b12.data_ptr(), 0,
-                    2 * S.H, 1, 2)
+                    2 * S.H, 1, 2, prefix + "w1.bias")
         self._desc_dev = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._ndesc = len(rows)
         self._tiles = tiles
+        self._desc_tile0 = [r[7] for r in rows] + [tiles]
         self.prep()
 
     def prep(self):
         """Refresh every bf16 compute copy from the fp32 masters (one kernel launch)."""
         ops.prep_weights(self._desc_dev, self._ndesc, self._tiles)
+        for hook in getattr(self, "prep_hooks", ()):
+            hook()
+        self._prepped_version = self.flat_p._version
+
+    def desc_runs(self, ranges):
+        """runs [d0, d1) of the weight-refresh table whose fp32 sources lie in the given flat ranges (the layers of a gradient bucket)"""
+        hit = [i for i, o in enumerate(self._desc_src) if any(lo <= o < hi for lo, hi in ranges)]
+        runs = []
+        for i in hit:
+            if runs and runs[-1][1] == i:
+                runs[-1][1] = i + 1
+            else:
+                runs.append([i, i + 1])
+        return [tuple(r) for r in runs]
+
+    def prep_runs(self, runs):
+        """refresh the bf16 compute copies of the table runs only (one launch per run): the per-bucket optimizer lane of the trainer"""
+        for d0, d1 in runs:
+            ops.prep_weights_range(self._desc_dev[d0:], d1 - d0, self._desc_tile0[d0], self._desc_tile0[d1] - self._desc_tile0[d0])
+
+    def mark_prepped(self):
+        """every compute copy is current (the trainer refreshed them bucket by bucket): LayerScale hooks + the version stamp"""
         for hook in getattr(self, "prep_hooks", ()):
             hook()
         self._prepped_version = self.flat_p._version
@@ -501,8 +526,8 @@ class Stack:
         buffer of a given size is allocated ONCE and kept for the lifetime of the stack: captured hipGraph segments bake its
         address, so it is only ever refreshed in place -- switching the plan off, or alternating between plans of different sizes
         (steps with / without SSL crops), never frees or moves a buffer a graph may still read."""
-        if plan is not None and not self.swiglu:
-            raise NotImplementedError("stochastic depth is implemented for SwiGLU ViT blocks only (not the GELU-Mlp FFN / the text tower)")
+        if plan is not None and self.style != "vit":
+            raise NotImplementedError("stochastic depth is a property of the ViT blocks (block.py:207-289); the text tower has none")
         if plan is None:
             if self.drop_plan is not None:
                 self.last_drop_plan = self.drop_plan  # introspection (tests replay the subsets of the step that just ran)
@@ -552,7 +577,7 @@ class Stack:
             qkv, o = ws.get(t + "qkv", (Mc, 3 * D), BF), ws.get(t + "o", (Mc, D), BF)
             lse = ws.get(t + "lse", (Mc * heads,), F32)
             xn2, st2 = ws.get(t + "xn2", (Mc, D), BF), ws.get(t + "st2", (Mc, 2), F32)
-            pre, hid = ws.get(t + "x12", (Mc, 2 * H), BF), ws.get(t + "hid", (Mc, H), BF)
+            pre, hid = ws.get(t + "x12", (Mc, 2 * H if self.swiglu else H), BF), ws.get(t + "hid", (Mc, H), BF)
             delta = ws.get("d.delta", (Mc, D), F32)
             # ---- attention branch on the kept images
             self._gather(x, segs, csegs, i, 0, xs1, None, 1.0)
@@ -572,7 +597,11 @@ class Stack:
             # ---- FFN branch on an independent subset
             self._gather(x, segs, csegs, i, 1, xs2, None, 1.0)
             ops.norm_fwd(xs2, b.n2w, b.n2b, xn2, st2, Mc, D, self.eps, self.kind)
-            ops.gemm_nt(xn2, b.w12.w12, hid, M=Mc, N=2 * H, K=D, c2=pre, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            if self.swiglu:
+                ops.gemm_nt(xn2, b.w12.w12, hid, M=Mc, N=2 * H, K=D, c2=pre, ldc2=2 * H, bias=b.w12.b12, epi=EPI_SWIGLU)
+            else:  # Mlp FFN (ffn_layer = "mlp", ffn.py:21-48): fc1 -> GELU -> fc2 on the kept images
+                ops.gemm_nt(xn2, b.fc.w, hid, M=Mc, N=H, K=D, c2=pre, ldc2=H, bias=b.fc.bias,
+                            epi=ops.EPI_QUICK_GELU if self.quick_gelu else EPI_GELU)
             ops.gemm_nt(hid, b.w3.w, delta, M=Mc, N=D, K=H, bias=b.w3.bias, gamma=b.ls2, epi=EPI_F32)
             self._scatter(delta, x, segs, csegs, i, 1, scales, accumulate=True)
             saved_all.append((xs1, xn1, st1, qkv, o, lse, xs2, xn2, st2, pre, hid))
@@ -609,7 +638,7 @@ class Stack:
         Mc = sum(k * N for k, N, _ in csegs)
         scale = 1.0 / math.sqrt(64.0)
         dh = ws.get("b.d.dh", (Mc, H), BF)
-        dpre = ws.get("b.d.dx12", (Mc, 2 * H), BF)
+        dpre = ws.get("b.d.dx12", (Mc, 2 * H if self.swiglu else H), BF)
         dxn = ws.get("b.d.dxn", (Mc, D), BF)
         d_o = ws.get("b.d.do", (Mc, D), BF)
         dqkv = ws.get("b.d.dqkv", (Mc, 3 * D), BF)
@@ -623,8 +652,12 @@ class Stack:
             # ---- FFN branch: d(delta2) = alpha * dy[kept rows]; the branch-input gradient lands on the same rows
             self._gather(dy, segs, csegs, i, 1, gdy, gdy_b, scales)
             linear_bwd(ws, "w3", b.w3, gdy_b, hid, Mc, dh, ls=(b.ls2, b.gls2) if b.ls2 is not None else None)
-            ops.swiglu_bwd(dh, pre, dpre, Mc, H)
-            linear_bwd(ws, "w12", None, dpre, xn2, Mc, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T, swiglu_h=H)
+            if self.swiglu:
+                ops.swiglu_bwd(dh, pre, dpre, Mc, H)
+                linear_bwd(ws, "w12", None, dpre, xn2, Mc, dxn, N=2 * H, K=D, gw=b.w12.gw1, gb=b.w12.gb1, wT=b.w12.w12T, swiglu_h=H)
+            else:
+                ops.gelu_bwd(dh, pre, dpre, Mc * H, quick=self.quick_gelu)
+                linear_bwd(ws, "fc", b.fc, dpre, xn2, Mc, dxn)
             ops.norm_bwd(dxn, xs2, b.n2w, st2, gdy, dxc, None, b.gn2w, b.gn2b, Mc, D, self.kind)   # dxc = dy[kept] + norm bwd
             self._scatter(dxc, dy, segs, csegs, i, 1, 1.0, accumulate=False)
             # ---- attention branch
@@ -812,7 +845,7 @@ class Stack:
         # it), issued at the start of block i - 1's backward so that it overlaps that block's dgrad / attention kernels; the dy
         # operands it reads (dpre, dmid_b, dqkv; dy_b already alternates) are therefore double-buffered by block parity
         grouped = WGRAD_GROUPED and M >= 256 and all(b.ls1 is None and b.ls2 is None for b in self.blocks) \
-            and ops.wgrad_group_fits(M, max(3 * D, 2 * H if vit else H))  # else: per-layer launches (ring-kernel fallback inside)
+            and ops.wgrad_group_fits(M, max(3 * D, 2 * H if vit else H)) and D % 8 == 0 and H % 8 == 0  # else: per-layer launches (ring-kernel fallback inside)
         par = (lambda i: f".{i & 1}") if grouped else (lambda i: "")
         dh = ws.get("b.dh", (M, H), BF)
         d_o = ws.get("b.do", (M, D), BF)
@@ -1024,7 +1057,9 @@ class TrunkEngine:
         """d_lat: bf16 [B*hw, 64] grad of latents(seg=lat_seg), or None.  Accumulates every trunk parameter gradient into
         store.flat_g.  Generator (see Stack.backward): yields "tail", then ("block", i) per block.
         want_dimg: also form the gradient w.r.t. the input images (PatchEmbed backward, embeddings.py:61-70: d_tokens[patch rows]
-        W_pe folded back to pixels) -- ctx.d_img[i] f32 [B_i,3,H_i,W_i] per item; masked patches get zero (they never saw the pixels)."""
+        W_pe folded back to pixels) -- ctx.d_img[i] f32 [B_i,3,H_i,W_i] for list item i (freshly allocated: this path is the eager
+        autograd boundary, never a captured segment; the caller pops the entry -- ctx.take_d_img(i) -- so the tensor does not outlive the
+        autograd call on the cached ctx); masked patches get zero (they never saw the pixels)."""
         st = self.store
         if ctx is not None:
             self._ctx = ctx
@@ -1049,7 +1084,7 @@ class TrunkEngine:
         else:
             dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs,
                                                         dy_colsum_done=self.stack.w3_colsum_target(self.depth - 1) is not None)
-        for g in c.segs:
+        for item, g in enumerate(c.segs):
             d_s, d_sb = dx0[g.row0:g.row0 + g.B * g.N], dx0_b[g.row0:g.row0 + g.B * g.N]
             if g.masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
                 ops.mask_rows_bwd(d_s, d_sb, g.masks, st.g(self.prefix + "mask_token"), g.B, g.N, D)
@@ -1062,7 +1097,7 @@ class TrunkEngine:
                 ops.gemm_nt(d_sb, self.pe.wT, dpt, M=g.B * g.hw, N=768, K=D, epi=EPI_F32, a_remap=(g.hw, 1))
                 dimg = torch.empty(g.B, 3, g.h * 16, g.w * 16, dtype=F32, device=st.device)
                 ops.col2im16(dpt, dimg, g.B, g.h * 16, g.w * 16)
-                c.__dict__.setdefault("d_img", {})[g.row0] = dimg
+                c.__dict__.setdefault("d_img", {})[item] = dimg
         OVERLAP.join()
 
 
@@ -1072,6 +1107,10 @@ class TrunkSeg:
 
 class TrunkCtx:
     """Saved state of one trunk forward (what backward() needs)."""
+
+    def take_d_img(self, item: int = 0):
+        """the input-image gradient of list item `item` formed by backward(want_dimg=True); removes it from the ctx"""
+        return self.__dict__.get("d_img", {}).pop(item)
 
 
 # =====================================================================================================================

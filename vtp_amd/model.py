@@ -158,7 +158,7 @@ class VTPModel(nn.Module):
             self.text_transformer = tt
             self.token_embedding = _holder()
             self.token_embedding.weight = _param(c.text_vocab_size, Dt)
-            self.positional_embedding = _param(c.text_context_length, Dt)
+            self.positional_embedding = _param(c.text_num_pos, Dt)
             self.ln_final = _norm(Dt, True)
             self.text_projection = _param(Dt, Dt)
             self.context_length, self.vocab_size = c.text_context_length, c.text_vocab_size
@@ -343,7 +343,7 @@ class VTPModel(nn.Module):
     def _ids(self, text: torch.Tensor, check_range: bool = True) -> torch.Tensor:
         """token ids -> int64 [B, context_length], contiguous, on the device; out-of-range ids raise (the embedding kernel indexes
         the table with them).  check_range costs one host sync: the inference API pays it, the trainer's hot path does not."""
-        T = self.config.text_context_length
+        T = self.config.text_num_pos  # (context_length + 1 with text_embed_cls: the reference's positional table has that many rows)
         if not isinstance(text, torch.Tensor) or text.ndim != 2 or text.shape[1] != T:
             raise ValueError(f"text must be [B, {T}] token ids, got {tuple(getattr(text, 'shape', ()))}")
         if not text.is_cuda:
@@ -498,8 +498,9 @@ class VTPModel(nn.Module):
             raise RuntimeError("CLIP not enabled. Set train_clip=True in config.")
         if ag.grad_mode(self):
             ids = self._ids(text)
-            f = ag.TextFeature.apply(ids, ag.anchor(self), self)
-            return ag.L2Normalize.apply(f) if normalize else f
+            f = ag.TextFeature.apply(ids, ag.anchor(self), self)  # [B, D_t]; text_pool_type = "none": [B * T, D_t] (every token)
+            f = ag.L2Normalize.apply(f) if normalize else f
+            return f.view(ids.shape[0], ids.shape[1], -1) if self.config.text_pool_type == "none" else f
         return self._clip_text_nograd(text, normalize)
 
     @torch.no_grad()
@@ -509,11 +510,16 @@ class VTPModel(nn.Module):
         f = self._text.forward(ids, train=False)
         if normalize:
             f, _ = self._clip.normalize(f, "txt")
-        return f.clone()
+        f = f.clone()
+        return f.view(ids.shape[0], ids.shape[1], -1) if self.config.text_pool_type == "none" else f  # per-token features [B, T, D_t]
 
     def get_clip_logits(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """modeling_vtp.py:312-333.  Inference: the [B_img, B_txt] logits come from the clip_logits kernel (exp(logit_scale) * I T^T,
         fp32); in training mode the same kernel inside autograd.ClipLogits (backward on the clip_grad kernels)."""
+        if self.config.text_pool_type == "none":
+            # the reference multiplies [B, D] image features with `text_features.T` of a [B, T, D] tensor and fails in the matmul
+            # (modeling_vtp.py:329): same error class, stated
+            raise RuntimeError("get_clip_logits needs pooled text features: text_pool_type = 'none' returns per-token features [B, T, D]")
         i = self.get_clip_image_feature(image, normalize=True)
         t = self.get_clip_text_feature(text, normalize=True)
         if ag.grad_mode(self):

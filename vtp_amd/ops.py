@@ -113,6 +113,11 @@ def prep_weights(descs, n, total_tiles):
     _lib.check(_lib_().vtp_prep_weights(_p(descs), n, total_tiles, _s()), "vtp_prep_weights")
 
 
+def prep_weights_range(descs_run, n, tile_base, n_tiles):
+    """descs_run: the descriptor table sliced at the run's first record (a view: rows [d0:d1] of the int64 [*, 8] table)"""
+    _lib.check(_lib_().vtp_prep_weights_range(_p(descs_run), n, tile_base, n_tiles, _s()), "vtp_prep_weights_range")
+
+
 def swiglu_bwd(dh, x12, dx12, M, H, db12=None):
     _lib.check(_lib_().vtp_swiglu_bwd(_p(dh), _p(x12), _p(dx12), _p(db12), M, H, _s()), "vtp_swiglu_bwd")
 
@@ -204,7 +209,11 @@ class WgradGroup:
         """dy bf16 [Ktok, N] (row stride dy.stride(0)), x bf16 [Ktok, K], gw f32 [N * K], gb f32 [N] or None (bias gradient =
         column sums of dy, fused).  swiglu_h: dy's columns are the 8|8-interleaved w1|w2 pre-activation gradients; the rows of gw
         (and gb) are w1's H rows followed by w2's."""
-        assert N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+        # limits of BOTH grouped kernels (16-B staging pieces, clamped tail columns): checked here because the kernels read the records
+        # from device memory and cannot refuse them (ADVICE r4) -- e.g. ffn_layer="mlp" with an odd int(D * ratio) takes the per-layer path
+        if N % 8 or K % 8 or dy.stride(0) % 8 or x.stride(0) % 8 or N < 8 or K < 8:
+            raise ValueError(f"WgradGroup.add: N = {N}, K = {K} and the leading dimensions ({dy.stride(0)}, {x.stride(0)}) must be multiples "
+                             "of 8 (use the per-layer weight-gradient path: linear_bwd without `defer`)")
         self.rows.append([dy.data_ptr(), x.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), dy.stride(0), x.stride(0), K,
                           N, K, -1 if swiglu_h else 0, swiglu_h, self.ntiles, int(accumulate), 0, 0, 0])
         self.ntiles += ((N + 255) // 256) * ((K + 255) // 256)
@@ -388,6 +397,12 @@ def center_ema(center, col_sum, inv_count, momentum, K, count=None):
 
 def ema_dev(t, s, n, momentum_dev):
     _lib.check(_lib_().vtp_ema_dev(_p(t), _p(s), n, _p(momentum_dev), _s()), "vtp_ema_dev")
+
+
+def adamw_ema_dev(p, g, m, v, teacher, n, hyper, nodecay4=None):
+    """AdamW over one gradient bucket with the EMA update of the teacher's copy of the same elements fused in (teacher: f32 [n] or
+    None; momentum = hyper[9]) -- the per-bucket optimizer lane of VTPTrainer"""
+    _lib.check(_lib_().vtp_adamw_ema_dev(_p(p), _p(g), _p(m), _p(v), _p(teacher), _p(nodecay4), n, _p(hyper), _s()), "vtp_adamw_ema_dev")
 
 
 # ---- LPIPS (vtp_amd/csrc/lpips.hip, conv mode of gemm.hip) ---------------------------------------------------------------

@@ -116,12 +116,15 @@ class GradBucketer:
         self.reduced_elems += hi - lo
         self.comm_bytes += (hi - lo) * 4
 
-    def wait(self):
-        for w, after in self.works:
+    def wait(self, works=None):
+        """wait for the given (work, after) pairs, or for everything launched since the last wait"""
+        mine = works is None
+        for w, after in (self.works if mine else works):
             w.wait()
             if after is not None:
                 after()
-        self.works = []
+        if mine:
+            self.works = []
 
     def all_gather_params(self, flat_p: torch.Tensor, recs):
         """Every rank contributes its (freshly updated) chunk of each bucket; afterwards rec.p_recv holds the whole bucket."""
@@ -153,6 +156,7 @@ class HostStager:
         self.device, self.n, self.i = device, slots, 0
         self.host = [None] * slots
         self.events = [None] * slots
+        self.wait_s = 0.0  # host seconds spent waiting for a slot's previous upload (back-pressure: the host runs AHEAD of the GPU)
 
     def upload(self, arrays: dict) -> dict:
         import numpy as np
@@ -165,7 +169,10 @@ class HostStager:
         slot = self.i
         self.i = (self.i + 1) % self.n
         if self.events[slot] is not None:
+            import time
+            t0 = time.perf_counter()
             self.events[slot].synchronize()
+            self.wait_s += time.perf_counter() - t0
         if self.host[slot] is None or self.host[slot].numel() < total:
             self.host[slot] = torch.empty(max(total * 2, 1 << 16), dtype=torch.uint8).pin_memory()
         h = self.host[slot]
@@ -205,6 +212,19 @@ def param_ranges(offsets, prefixes: Sequence[str]) -> List[Tuple[int, int]]:
         if any(name.startswith(p) for p in prefixes):
             r.append((o, o + (k + 3) // 4 * 4))
     return merge_ranges(r)
+
+
+def lane_pieces(ranges: Sequence[Tuple[int, int]], pairs: Sequence[Tuple[int, int, int]]) -> List[Tuple[int, int, Optional[int]]]:
+    """Cut the flat ranges of a gradient bucket at the borders of the EMA-tracked parameter groups.  pairs = [(teacher_lo, student_lo,
+    student_hi)]: the teacher's copy of student element x in [student_lo, student_hi) is element teacher_lo + (x - student_lo).  Returns
+    [(lo, hi, teacher_lo_of_the_piece | None)]: every piece lies inside one group (fused AdamW + EMA) or outside all of them."""
+    pieces = []
+    for lo, hi in ranges:
+        cuts = sorted({lo, hi} | {x for _, slo, shi in pairs for x in (slo, shi) if lo < x < hi})
+        for a, b in zip(cuts, cuts[1:]):
+            tl = next((tlo + (a - slo) for tlo, slo, shi in pairs if slo <= a and b <= shi), None)
+            pieces.append((a, b, tl))
+    return pieces
 
 
 NO_DECAY_NAMES = ("logit_scale", "logit_bias", "cls_token", "mask_token", "positional_embedding", "storage_tokens")
@@ -310,6 +330,16 @@ class VTPTrainer:
                                      force=force_collectives)
         self.shard_optimizer = self.bucketer.shard
         self._shard_layout = None  # bucket boundaries of the first sharded step (chunk ownership of the Adam moments)
+        # OPTIMIZER LANE (round 5; VTP_OPT_OVERLAP=0 restores the serial leg): as soon as the gradients of a bucket are final (and,
+        # with several ranks, reduced) its fused AdamW + EMA-teacher update and the refresh of ITS bf16 weight copies run on a side
+        # stream beside the backward of the remaining layers, instead of one AdamW + one EMA + one refresh launch over everything
+        # after the last backward kernel (2.6 ms of a 46.7 ms step, serial).  The step-start gradient zeroing likewise runs on a side
+        # stream under the forward pass.  Replicated-AdamW mode only (the rank-sharded optimizer keeps its own leg).
+        self.overlap_opt = (not self.shard_optimizer) and os.environ.get("VTP_OPT_OVERLAP", "1") not in ("0", "false", "off")
+        self._opt_stream = self._zero_stream = None
+        self._opt_plans = {}
+        self._opt_busy = self._zero_busy = False
+        self._works_prev = []  # (work, after) pairs of the previous bucket event's reductions (_handle)
         self.collectives = self.bucketer.active  # world > 1, or a one-rank group with force_collectives
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
         self._comm_events = []
@@ -326,6 +356,8 @@ class VTPTrainer:
             self._clip_unsupported = ("the fused trainer implements the cls-token / un-bottlenecked CLIP image feature only "
                                       "(vision_clip_feat='cls', vision_bottleneck_ae_only=True); other settings train through "
                                       "the autograd path (model(...); loss.backward())")
+        elif self.text is not None and model.config.text_pool_type == "none":
+            self._clip_unsupported = "the contrastive objective needs pooled text features (text_pool_type argmax | first | last)"
         else:
             self._clip_unsupported = None
         self.sync_replicas()
@@ -404,6 +436,7 @@ class VTPTrainer:
         dist = self.bucketer.dist
         K, D = head.K, self.trunk.D
         out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
+        self._zero_join()  # the gradient buffer was zeroed under the forward passes; the head backward below is its first writer
         Tt, Ts, Tm, B2, nl = out["Tt"], out["Ts"], out["Tm"], out["B2"], out["nl"]
         ws = out["ws"]
         t_logits, s_logits = out["teacher_logits"], out["student_logits"]
@@ -525,13 +558,101 @@ class VTPTrainer:
         return dict(**{"global": global_crops, "local": local_crops}, masks=masks_dev, plan=plan, dev=up)
 
     def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None, rec_images=None):
-        """_step_body plus the bookkeeping of which flat ranges have been handed to the gradient exchange so far (known at
-        generator time, i.e. also while the body is being captured into hipGraph segments and no collective runs)."""
+        """_step_body plus (a) the bookkeeping of which flat ranges have been handed to the gradient exchange so far (known at
+        generator time, i.e. also while the body is being captured into hipGraph segments and no collective runs) and (b) the
+        OPTIMIZER LANE: the update of a bucket is enqueued on a side stream `lag` bucket events after the event that announced it
+        -- lag 1 without collectives (the gradients are final at the announcement), lag 2 with them (the driver launches the
+        all-reduce of event k at event k and waits for it at event k + 1, when it has had a whole segment of backward to complete:
+        `_handle`).  The side stream is forked from the main stream right behind an event and joined in front of the next one (a
+        yield ends a hipGraph segment: nothing forked may be left open there); what is still queued after the last event runs on
+        the main stream in the optimizer leg of the body."""
         self._reduced_ranges = []
+        self._opt_queue, self._opt_done = [], []
+        self._opt_ema = ssl is not None
+        lag = 2 if self.collectives else 1
         for ev in self._step_body(images, text, ssl, rec_images):
-            if not callable(ev):
-                self._reduced_ranges += merge_ranges([r for k in ev if k != "FINAL" for r in self._bucket_plan[k]])
+            self._opt_join()
+            if callable(ev):
+                yield ev
+                continue
+            keys = [k for k in ev if k != "FINAL"]
+            self._reduced_ranges += merge_ranges([r for k in keys for r in self._bucket_plan[k]])
             yield ev
+            if self.overlap_opt and "FINAL" not in ev:
+                self._opt_queue.append(keys)
+                while len(self._opt_queue) >= lag:
+                    self._opt_launch(self._opt_queue.pop(0))
+            elif self.overlap_opt:
+                self._opt_queue.append(keys)  # the last buckets: updated by the body's optimizer leg, on the main stream
+
+    # ---- optimizer lane -----------------------------------------------------------------------------------------------------
+    def _opt_plan(self, keys, ema: bool):
+        """static plan of one bucket update: [(lo, hi, teacher_lo | None)] pieces of the flat buffers (a piece lies inside one
+        EMA-tracked parameter group or outside all of them) and the runs of the weight-refresh table that hold the bucket's layers
+        (student and, with `ema`, the teacher's copies of them)"""
+        ck = (tuple(keys), ema)
+        plan = self._opt_plans.get(ck)
+        if plan is None:
+            st = self.store
+            rs = merge_ranges([r for k in keys for r in self._bucket_plan[k]])
+            pairs = []
+            if ema:
+                from .vtp import _range
+                for t_pref, s_pref in self.model.ema_pairs():
+                    (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
+                    assert thi - tlo == shi - slo
+                    pairs.append((tlo, slo, shi))
+            pieces = lane_pieces(rs, pairs)
+            runs = st.desc_runs(rs) + st.desc_runs([(tl, tl + b - a) for a, b, tl in pieces if tl is not None])
+            plan = self._opt_plans[ck] = (pieces, runs)
+        return plan
+
+    def _opt_update(self, keys):
+        """fused AdamW (+ EMA teacher) over the bucket's ranges and the refresh of its bf16 weight copies, on the current stream"""
+        st = self.store
+        pieces, runs = self._opt_plan(keys, self._opt_ema)
+        for a, b, tl in pieces:
+            ops.adamw_ema_dev(st.flat_p[a:b], st.flat_g[a:b], self.m[a:b], self.v[a:b], None if tl is None else st.flat_p[tl:tl + b - a],
+                              b - a, self.hyper, None if self.nodecay4 is None else self.nodecay4[a // 4:b // 4])
+        st.prep_runs(runs)
+        self._opt_done += [(a, b) for a, b, _ in pieces]
+
+    def _opt_launch(self, keys):
+        if not keys:
+            return
+        if not OVERLAP.enabled:  # VTP_OVERLAP=0 (single-stream attribution profiles): same kernels, in line
+            return self._opt_update(keys)
+        main = torch.cuda.current_stream()
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream()
+        self._opt_stream.wait_stream(main)
+        with torch.cuda.stream(self._opt_stream):
+            self._opt_update(keys)
+        self._opt_busy = True
+
+    def _opt_join(self):
+        if self._opt_busy:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._opt_busy = False
+
+    def _zero_grads_async(self):
+        """step-start zeroing of the flat gradient buffer (1.7 GB for the full VTP-B step) on a side stream, under the forward pass;
+        _zero_join() sits in front of the first kernel that writes a gradient"""
+        if not (self.overlap_opt and OVERLAP.enabled):
+            self.store.zero_grad()
+            return
+        main = torch.cuda.current_stream()
+        if self._zero_stream is None:
+            self._zero_stream = torch.cuda.Stream()
+        self._zero_stream.wait_stream(main)
+        with torch.cuda.stream(self._zero_stream):
+            self.store.zero_grad()
+        self._zero_busy = True
+
+    def _zero_join(self):
+        if self._zero_busy:
+            torch.cuda.current_stream().wait_stream(self._zero_stream)
+            self._zero_busy = False
 
     def _separate_rec(self, images, text, rec_images) -> bool:
         """does the reconstruction objective need its own trunk item?  (another tensor than the clip objective's, or another
@@ -549,7 +670,7 @@ class VTPTrainer:
         B, _, H, W = rec_img.shape
         h, w = H // 16, W // 16
         N = h * w + 1
-        st.zero_grad()
+        self._zero_grads_async()
         self.loss_sum.zero_()
         self.clip_loss_sum.zero_()
         self._deferred = []  # work that only has to be done by the end of the step (runs in the optimizer leg, behind every collective)
@@ -558,6 +679,7 @@ class VTPTrainer:
             xnf_all = (yield from self._ssl_gen(ssl, lead_images=leads))["xnf"]
         else:
             xnf_all = self.trunk.forward_list([(im, None) for im in leads], train=True)
+            self._zero_join()
         xnf = xnf_all[:Bc * Nc]  # rows of the clip item (item 0; the shared item when rec and clip see the same pass)
         # the text tower's GEMMs are small (M = 77 B rows): it is issued on its own stream (with its own wgrad side stream,
         # OVERLAP lane 1) so that it runs concurrently with the decoder forward / the first decoder-backward blocks
@@ -708,12 +830,23 @@ class VTPTrainer:
             yield lambda: self.bucketer.all_gather_params(st.flat_p, recs)
             for rec in recs:
                 st.flat_p[rec.lo:rec.hi].copy_(rec.p_recv[:rec.hi - rec.lo])
+        elif self.overlap_opt:
+            # optimizer lane: most buckets were updated beside the backward; the last ones (announced with / right before FINAL) here
+            for keys in self._opt_queue:
+                if keys:
+                    self._opt_update(keys)
+            self._opt_queue = []
+            if merge_ranges(self._opt_done) != list(ranges):
+                raise RuntimeError(f"optimizer lane: updated ranges {merge_ranges(self._opt_done)} differ from the step's parameter ranges {list(ranges)}")
         else:
             for lo, hi in ranges:
                 ops.adamw_dev(st.flat_p[lo:hi], st.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], None, hi - lo, self.hyper,
                               None if self.nodecay4 is None else self.nodecay4[lo // 4:hi // 4])
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
+        if self.overlap_opt:  # EMA and the weight refresh rode along bucket by bucket
+            st.mark_prepped()
+            return
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
             from .vtp import _range
             for t_pref, s_pref in self.model.ema_pairs():  # trunk, proj (legacy teacher_proj, vtp.py:396-398), dino_head
@@ -828,9 +961,17 @@ class VTPTrainer:
             self._timed(ev)
             return
         final = "FINAL" in ev
+        lane = self.overlap_opt and self.collectives
+        if lane and self._works_prev:
+            # optimizer lane: the reductions launched at the PREVIOUS bucket event have had a whole segment of backward to complete;
+            # the next segment updates that bucket (lag 2 of _step_gen), so the main stream takes them in now
+            prev, self._works_prev = self._works_prev, []
+            self._timed(lambda: self.bucketer.wait(prev))
         self._reduce([k for k in ev if k != "FINAL"])
         if final:
             self._timed(self.bucketer.wait)  # the generator's next (last) leg is the optimizer
+        elif lane:
+            self._works_prev, self.bucketer.works = self.bucketer.works, []
 
     def step(self, images: torch.Tensor, text: Optional[torch.Tensor] = None, ssl: Optional[dict] = None,
              reconstruction_image: Optional[torch.Tensor] = None):
@@ -855,6 +996,7 @@ class VTPTrainer:
         B, _, H, W = (images if rec_images is None else rec_images).shape
         self._set_hyper()
         self._draw_drop_plans(images, text, ssl, rec_images)
+        self._works_prev = []
         try:
             if self.use_graphs:
                 self._step_graphs(images, text, ssl, rec_images)
