@@ -40,15 +40,43 @@ def rope_periods(head_dim: int = 64, base: float = 100.0, dtype=torch.bfloat16) 
     return base ** (2 * torch.arange(head_dim // 4, dtype=dtype) / (head_dim // 2))
 
 
-def rope_table(H: int, W: int, periods: Tensor) -> Tuple[Tensor, Tensor]:
-    """(sin, cos), each [H*W, D_head], in periods.dtype -- 'separate' coordinate normalisation,
-    no train-time augmentation.  embeddings.py:131-180 (exact op order, so bf16 rounding matches)."""
+def rope_aug_draw(shift: Optional[float], jitter: Optional[float], rescale: Optional[float], dtype=torch.bfloat16, device="cpu",
+                  generator=None) -> Dict[str, Optional[Tensor]]:
+    """One call's random draws of RopePositionEmbedding.forward in training mode (embeddings.py:155-171), with the reference's own
+    torch calls in its order -- shift: U(-s, s) per axis; jitter: exp(U(-ln j, ln j)) per axis; rescale: exp(U(-ln r, ln r)), one
+    value -- drawn in `dtype` (the rope dtype, bf16).  With generator=None the GLOBAL generator is consumed exactly as the reference
+    consumes it (the pinning test seeds it the same way on both sides)."""
+    import numpy as np
+    dd = {"dtype": dtype, "device": device}
+    out: Dict[str, Optional[Tensor]] = {"shift": None, "jitter": None, "rescale": None}
+    if shift is not None:
+        out["shift"] = torch.empty(2, **dd).uniform_(-shift, shift, generator=generator)
+    if jitter is not None:
+        jm = np.log(jitter)
+        out["jitter"] = torch.empty(2, **dd).uniform_(-jm, jm, generator=generator).exp()
+    if rescale is not None:
+        rm = np.log(rescale)
+        out["rescale"] = torch.empty(1, **dd).uniform_(-rm, rm, generator=generator).exp()
+    return out
+
+
+def rope_table(H: int, W: int, periods: Tensor, aug: Optional[Dict[str, Optional[Tensor]]] = None) -> Tuple[Tensor, Tensor]:
+    """(sin, cos), each [H*W, D_head], in periods.dtype -- 'separate' coordinate normalisation.
+    embeddings.py:131-180 (exact op order, so bf16 rounding matches).  aug = rope_aug_draw(...): the train-time coordinate
+    augmentations (:155-171) with GIVEN draws -- shift added, then the per-axis jitter and the global rescale multiplied in place."""
     dd = {"dtype": periods.dtype, "device": periods.device}  # device-aware: the GPU-autocast comparator of the tests
     coords_h = torch.arange(0.5, H, **dd) / H
     coords_w = torch.arange(0.5, W, **dd) / W
     coords = torch.stack(torch.meshgrid(coords_h, coords_w, indexing="ij"), dim=-1)
     coords = coords.flatten(0, 1)
     coords = 2.0 * coords - 1.0
+    if aug is not None:
+        if aug.get("shift") is not None:
+            coords += aug["shift"].to(**dd)[None, :]
+        if aug.get("jitter") is not None:
+            coords *= aug["jitter"].to(**dd)[None, :]
+        if aug.get("rescale") is not None:
+            coords *= aug["rescale"].to(**dd)
     angles = 2 * math.pi * coords[:, :, None] / periods[None, None, :]
     angles = angles.flatten(1, 2)
     angles = angles.tile(2)
@@ -176,9 +204,11 @@ def patch_embed(img: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottleneck: bool = True,
-                  masks: Optional[Tensor] = None, pre: str = "trunk.", drop=None, lin=_plain_linear) -> Dict[str, Tensor]:
+                  masks: Optional[Tensor] = None, pre: str = "trunk.", drop=None, lin=_plain_linear, rope_aug=None) -> Dict[str, Tensor]:
     """DinoVisionTransformerWithBottleneck.forward(is_training=True) for ONE resolution --
-    vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79."""
+    vision_transformer.py:189-264, vision_transformer_bottleneck.py:48-79.
+    rope_aug = [rope_aug_draw(...) per block]: the trunk calls rope_embed INSIDE its block loop (vision_transformer.py:228-233), so with
+    train-time augmentations every block rotates with its own freshly drawn tables."""
     x = patch_embed(img, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"])
     B, hw, D = x.shape
     H, W = img.shape[-2] // 16, img.shape[-1] // 16
@@ -190,6 +220,8 @@ def trunk_forward(sd: Dict[str, Tensor], img: Tensor, num_heads: int, use_bottle
     x = torch.cat([cls.expand(B, -1, -1), x], dim=1)  # :210-217 (no storage tokens)
     rope = rope_table(H, W, sd[pre + "rope_embed.periods"])
     for i in range(_depth(sd, pre + "blocks.")):
+        if rope_aug is not None:
+            rope = rope_table(H, W, sd[pre + "rope_embed.periods"], rope_aug[i])
         x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "rmsnorm", drop=None if drop is None else drop[i], lin=lin)
     xn = rmsnorm(x, sd[pre + "norm.weight"], 1e-5)  # :246
     cls_t, patch_t = xn[:, 0], xn[:, 1:]
@@ -237,12 +269,14 @@ def reconstruction_latents(sd, img, num_heads, lin=_plain_linear) -> Tensor:
 # pixel decoder -- vtp/models/decoders/pixel_decoder.py:134-162
 # --------------------------------------------------------------------------------------------
 def decoder_forward(sd: Dict[str, Tensor], latents: Tensor, num_heads: int, pre: str = "pixel_decoder.", drop=None,
-                    lin=_plain_linear) -> Tensor:
+                    lin=_plain_linear, rope_aug=None) -> Tensor:
+    """DinoV3PixelDecoder.forward -- pixel_decoder.py:134-162.  rope_aug = ONE rope_aug_draw(...): the decoder evaluates rope_embed once,
+    in front of its block loop (:144), so all blocks share one augmented table."""
     B, _, H, W = latents.shape
     x = F.conv2d(latents, sd[pre + "proj_in.weight"], sd[pre + "proj_in.bias"])  # :138
     D = x.shape[1]
     x = x.flatten(2).transpose(1, 2)  # :141
-    rope = rope_table(H, W, sd[pre + "rope_embed.periods"])  # :144
+    rope = rope_table(H, W, sd[pre + "rope_embed.periods"], rope_aug)  # :144
     for i in range(_depth(sd, pre + "blocks.")):
         x = vit_block(x, sd, f"{pre}blocks.{i}.", num_heads, rope, "layernorm", drop=None if drop is None else drop[i], lin=lin)
     x = layernorm(x, sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-6)  # :151

@@ -146,16 +146,18 @@ def test_bench_step_parity_at_b32():
     gc, lc = bench.synthetic_crops(B, res, dev, 777)
     masks, upper = bench.MaskStream(B, res, 555).draw()
     for rep in range(2):  # first call: eager warm-up + capture + replay; second: replay only
+        # the teacher-softmax centres this step reads: zeros at step 0, the EMA of the first batch's statistics at the replayed step
+        c_d, c_i = trainer.center_dino.detach().clone(), trainer.center_ibot.detach().clone()
         ssl = trainer.prepare_ssl(gc, lc, masks, upperbound=upper)
         l1, lcl = trainer.step(img, txt, ssl)
     torch.cuda.synchronize()
+    assert float(c_d.abs().max()) > 0, "the replayed step must see the centres the first step left"
     assert trainer._graphs, "the step must have run from captured hipGraph segments"
     M = sum(g.B * g.N for g in trainer.trunk.ctx().segs)
     assert M == 32 * 257 + 64 * 257 + 256 * 37 == 34144
     ours_loss = (float(l1), float(lcl), float(trainer.ssl_loss_sum))
     ours = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None and not n.startswith("teacher_")}
     masks_t = masks.bool() if torch.is_tensor(masks) else torch.as_tensor(np.asarray(masks), dtype=torch.bool)
-    c_d, c_i = torch.zeros(K), torch.zeros(K)  # the trainer's centres at step 0
     del trainer, model
     torch.cuda.empty_cache()
     # ---- the oracle on the same inputs, fp32 and under cuda autocast, on the GPU
