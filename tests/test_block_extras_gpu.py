@@ -206,6 +206,62 @@ def test_stochastic_depth_with_mlp_ffn_vs_oracle():
         assert abs(a - b) < 2e-3 * abs(a)
 
 
+def test_rope_train_time_augmentations_vs_oracle():
+    """RopePositionEmbedding shift / jitter / rescale (embeddings.py:155-171; `pos_embed_rope_*_coords` of the ViT classes, reachable
+    through the legacy YAML): in training the trunk draws new coordinates per BLOCK (rope_embed sits inside its block loop,
+    vision_transformer.py:228-233), the pixel decoder once per forward (pixel_decoder.py:144).  The step's loss and gradients against
+    the oracle evaluated with the SAME draws (read back from the engines; the oracle's augmented tables are pinned to the real class
+    bit for bit by tests/test_oracle_vs_reference.py), evaluation passes stay un-augmented, graphs agree with eager."""
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPTrainer
+    kw = dict(vision_rope_shift_coords=0.2, vision_rope_jitter_coords=1.3, vision_rope_rescale_coords=1.5,
+              decoder_rope_shift_coords=0.1, decoder_rope_rescale_coords=1.2)
+    m, sd = _model(None, **kw)
+    B = 3
+    img = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    m.eval()
+    with torch.no_grad():  # evaluation: plain tables
+        lat = m.get_reconstruction_latents(img.to(DEV))
+        lat_ref = O.reconstruction_latents(sd, img, 2)
+    assert relF(lat, lat_ref) < 1.5e-2
+    m.train()
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0)
+    loss = tr.step_rec(img.to(DEV))
+    torch.cuda.synchronize()
+    d_tr, d_dec = tr.trunk.rope_aug.last_draws, tr.decoder.rope_aug.last_draws
+    assert len(d_tr) == tr.trunk.depth and len(d_tr[0]) == 1 and len(d_dec) == 1
+    assert not torch.equal(d_tr[0][0]["shift"], d_tr[1][0]["shift"]), "every block draws its own coordinates"
+    aug_tr, aug_dec = [row[0] for row in d_tr], d_dec[0][0]
+
+    def ref_loss(s_):
+        out = O.trunk_forward(s_, img, 2, use_bottleneck=True, rope_aug=aug_tr)
+        return O.l1_loss(O.decoder_forward(s_, out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, rope_aug=aug_dec), img)
+
+    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    loss_ref = ref_loss(ref)
+    loss_ref.backward()
+    ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        l16 = ref_loss(ref16)
+    l16.backward()
+    with torch.no_grad():
+        plain = O.rec_train_loss(sd, img, 2, 2)
+    print(f"RoPE augmentation: loss ours {float(loss):.5f} oracle (same draws) {float(loss_ref):.5f} oracle without augmentation {float(plain):.5f}")
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+    _compare_grads(m, ref, ["trunk.blocks.0.attn.qkv.weight", "trunk.blocks.2.attn.qkv.bias", "trunk.blocks.1.attn.proj.weight",
+                            "trunk.blocks.0.mlp.w3.weight", "trunk.patch_embed.proj.weight", "pixel_decoder.blocks.0.attn.qkv.weight",
+                            "pixel_decoder.blocks.1.mlp.w1.weight", "pixel_decoder.proj_in.weight"], 3e-2, ref16)
+    # fresh draws every step; the hipGraph path re-draws into the static buffers before each replay
+    tr.step_rec(img.to(DEV))
+    assert not torch.equal(tr.trunk.rope_aug.last_draws[0][0]["shift"], d_tr[0][0]["shift"])
+    m2, _ = _model(None, **kw)
+    t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, use_graphs=True)
+    ls = [float(t2.step_rec(img.to(DEV))) for _ in range(4)]
+    draws = t2.trunk.rope_aug.last_draws
+    assert all(l == l for l in ls) and ls[-1] < ls[0] + 0.05 and len(draws) == t2.trunk.depth
+    print("RoPE augmentation, graph path losses:", ls)
+
+
 def test_qk_norm_forward_and_gradients_vs_oracle():
     """use_qk_norm in trunk and decoder: encode / decode outputs and the rec-step gradients (incl. the q / k norm weights) against
     the oracle's autograd; eager == hipGraph segments"""

@@ -75,6 +75,47 @@ def test_range_helpers():
     assert param_ranges(offs, ("trunk.", "pixel_decoder.")) == [(0, 8), (12, 20)]
 
 
+def test_rope_augmentation_host_tables_and_config(tmp_path):
+    """train-time RoPE augmentations (embeddings.py:155-171): the engine's host tables equal the oracle's (which the reference pins) for
+    the same draws, bit for bit; the options travel as extra VTPConfig keys and through the legacy YAML's pos_embed_rope_*_coords"""
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPConfig
+    from vtp_amd.engine import RopeAugmenter, _rope_host
+    per = O.rope_periods()
+    aug = RopeAugmenter(per, 3, True, 0.2, 1.3, 1.5, seed=5)
+    assert aug.active and not RopeAugmenter(per, 3, True, None, None, None).active
+    for hw in ((4, 6), (16, 16)):
+        d = aug._draw()
+        assert d["shift"].dtype == torch.bfloat16 and float(d["shift"].abs().max()) <= 0.2 and 1 / 1.3 <= float(d["jitter"].min()) and float(d["rescale"]) <= 1.5
+        s1, c1 = _rope_host(per, *hw, d)
+        s2, c2 = O.rope_table(*hw, per, d)
+        assert torch.equal(s1, s2.to(torch.bfloat16)) and torch.equal(c1, c2.to(torch.bfloat16))
+    s1, _ = _rope_host(per, 16, 16, None)
+    assert torch.equal(s1, O.rope_table(16, 16, per)[0].to(torch.bfloat16))
+    c = VTPConfig(vision_rope_shift_coords=0.1, decoder_rope_jitter_coords=1.2)
+    assert c.vision_rope_shift_coords == 0.1 and c.vision_rope_jitter_coords is None and c.decoder_rope_jitter_coords == 1.2
+    assert VTPConfig.from_dict(c.to_dict()).decoder_rope_jitter_coords == 1.2
+    assert not [k for k in VTPConfig().to_dict() if "rope" in k]  # defaults: the reference's HF config keys only
+    with pytest.raises(ValueError):
+        VTPConfig(vision_rope_jitter_coords=0.5)
+    import yaml
+    y = {"data": {"image_size": 64},
+         "training": {"train_clip": True, "train_reconstruction": True},
+         "vtp_model": {"vision_encoder": {"patch_size": 16, "embed_dim": 128, "depth": 2, "num_heads": 2, "mlp_ratio": 4.0, "ffn_layer": "swiglu",
+                                          "norm_type": "rmsnorm", "vit_feature_bottleneck": 64, "bottleneck_ae_only": True, "clip_feat": "cls",
+                                          "pos_embed_rope_shift_coords": 0.25, "pos_embed_rope_rescale_coords": 2.0},
+                       "text_encoder": {"context_length": 16, "vocab_size": 512, "embed_dim": 128, "heads": 2, "layers": 2, "mlp_ratio": 4.0,
+                                        "embed_cls": False, "pad_id": 0, "no_causal_mask": False, "pool_type": "argmax", "proj_type": "linear",
+                                        "proj_bias": False, "output_tokens": False, "quick_gelu": False},
+                       "pixel_decoder": {"embed_dim": 128, "num_heads": 2, "depth": 2, "ffn_layer": "swiglu", "norm_layer": "layernorm",
+                                         "pos_embed_rope_jitter_coords": 1.1}}}
+    f = tmp_path / "vtp.yaml"
+    f.write_text(yaml.safe_dump(y))
+    c = VTPConfig.from_vtp_yaml(str(f))
+    assert (c.vision_rope_shift_coords, c.vision_rope_jitter_coords, c.vision_rope_rescale_coords) == (0.25, None, 2.0)
+    assert c.decoder_rope_jitter_coords == 1.1
+
+
 def test_optimizer_lane_pieces_and_table_runs():
     """per-bucket optimizer lane (vtp_amd/train.py): a bucket's flat ranges are cut at the borders of the EMA-tracked groups, each piece
     carries the offset of the teacher's copy; ParamStore.desc_runs picks the weight-refresh records whose sources lie in given ranges"""

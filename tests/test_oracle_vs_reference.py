@@ -315,6 +315,42 @@ def test_text_embed_cls_and_pool_none_match_reference(embed_cls, pool):
             m.get_clip_logits(torch.randn(3, 3, 64, 64), text)
 
 
+def test_rope_train_time_augmentations_match_reference():
+    """RopePositionEmbedding's shift / jitter / rescale of the patch coordinates in training mode (embeddings.py:155-171): the oracle's
+    augmented tables and where the towers draw them -- the trunk inside its block loop (vision_transformer.py:228-233: new coordinates
+    per block), the pixel decoder once per forward (pixel_decoder.py:144) -- against the real class consuming the same global RNG
+    stream: bit-identical latents and reconstructions"""
+    ref = load_reference()
+    torch.manual_seed(0)
+    m = ref.VTPModel(ref.VTPConfig(**TINY))
+    sd = m.state_dict()
+    for mod in (m.trunk.rope_embed, m.pixel_decoder.rope_embed):
+        mod.shift_coords, mod.jitter_coords, mod.rescale_coords = 0.1, 1.2, 1.5
+    m.train()
+    img = torch.randn(2, 3, 64, 64)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        lat_ref = m.get_reconstruction_latents(img)
+    torch.manual_seed(11)
+    draws = [O.rope_aug_draw(0.1, 1.2, 1.5) for _ in range(TINY["vision_depth"])]
+    with torch.no_grad():
+        pt = O.trunk_forward(sd, img, 2, rope_aug=draws)["x_norm_patchtokens"]
+        lat = pt.transpose(1, 2).reshape(2, -1, 4, 4)
+        plain = O.reconstruction_latents(sd, img, 2)
+    assert torch.equal(lat, lat_ref) and not torch.allclose(plain, lat_ref, atol=1e-5)
+    torch.manual_seed(12)
+    with torch.no_grad():
+        rec_ref = m.get_latents_decoded_images(lat_ref)
+    torch.manual_seed(12)
+    d = O.rope_aug_draw(0.1, 1.2, 1.5)
+    with torch.no_grad():
+        rec = O.decoder_forward(sd, lat_ref, 2, rope_aug=d)
+    assert torch.equal(rec, rec_ref)
+    m.eval()  # evaluation mode: no augmentation
+    with torch.no_grad():
+        torch.testing.assert_close(O.reconstruction_latents(sd, img, 2), m.get_reconstruction_latents(img), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("vis,dec", [("mlp", "mlp"), ("swiglu64", "swiglu")])
 def test_ffn_layer_variants_match_reference(vis, dec):
     """ffn_layer = "mlp" (GELU Mlp, ffn.py:21-48) and the aligned SwiGLU widths (vision_transformer.py:22-28): parameter names /

@@ -8,6 +8,10 @@ import os
 from typing import Optional
 
 
+ROPE_AUG_KEYS = ("vision_rope_shift_coords", "vision_rope_jitter_coords", "vision_rope_rescale_coords",
+                 "decoder_rope_shift_coords", "decoder_rope_jitter_coords", "decoder_rope_rescale_coords")
+
+
 class VTPConfig:
     model_type = "vtp"
 
@@ -60,6 +64,12 @@ class VTPConfig:
             loc.pop(k, None)
         self.__dict__.update(loc)
         self.extra = dict(kwargs)  # unknown keys of a HF config.json (transformers_version, architectures, ...)
+        # train-time RoPE coordinate augmentations (RopePositionEmbedding shift / jitter / rescale, embeddings.py:155-171): constructor
+        # arguments `pos_embed_rope_*_coords` of the reference's ViT classes that its HF config does not carry -- they arrive through the
+        # legacy training YAML (vision_encoder / pixel_decoder sections are passed on as **kwargs, vtp.py:196-237; from_vtp_yaml below)
+        # or as extra keyword arguments here; None = off (the reference's default)
+        for k in ROPE_AUG_KEYS:
+            setattr(self, k, self.extra.pop(k, None))
         self._validate()
 
     # what the gfx950 kernels implement today; anything else is rejected loudly rather than silently approximated
@@ -79,6 +89,10 @@ class VTPConfig:
         need(self.vision_clip_feat in ("cls", "pooled"), f"Invalid vision_clip_feat: {self.vision_clip_feat}")
         need(self.text_pool_type in ("argmax", "first", "last", "none"), "text_pool_type must be argmax | first | last | none")
         need(self.text_proj_type == "linear" and not self.text_proj_bias, "text projection must be the bias-free matrix")
+        for k in ROPE_AUG_KEYS:
+            v = getattr(self, k)
+            need(v is None or (float(v) > 0 if k.endswith("shift_coords") else float(v) >= 1.0),
+                 f"{k} must be None, or > 0 (shift) / >= 1 (jitter, rescale: log-uniform in [1/v, v])")
 
     @property
     def text_num_pos(self) -> int:
@@ -88,7 +102,7 @@ class VTPConfig:
         return int(self.text_context_length) + (1 if self.text_embed_cls else 0)
 
     def to_dict(self):
-        d = {k: v for k, v in self.__dict__.items() if k != "extra"}
+        d = {k: v for k, v in self.__dict__.items() if k != "extra" and not (k in ROPE_AUG_KEYS and v is None)}
         d["model_type"] = self.model_type
         return d
 
@@ -128,9 +142,15 @@ class VTPConfig:
         ("decoder", "embed_dim"): "decoder_embed_dim", ("decoder", "num_heads"): "decoder_num_heads", ("decoder", "depth"): "decoder_depth",
         ("decoder", "ffn_layer"): "decoder_ffn_layer", ("decoder", "norm_layer"): "decoder_norm_layer",
         ("decoder", "layerscale_init"): "decoder_init_values", ("decoder", "use_qk_norm"): "decoder_use_qk_norm",
+        # (not in the reference's classmethod, whose HF config has no such fields: the legacy class forwards these sections' keys to the
+        # ViT constructors as they are, vtp.py:196-237)
+        ("vision", "pos_embed_rope_shift_coords"): "vision_rope_shift_coords", ("vision", "pos_embed_rope_jitter_coords"): "vision_rope_jitter_coords",
+        ("vision", "pos_embed_rope_rescale_coords"): "vision_rope_rescale_coords",
+        ("decoder", "pos_embed_rope_shift_coords"): "decoder_rope_shift_coords", ("decoder", "pos_embed_rope_jitter_coords"): "decoder_rope_jitter_coords",
+        ("decoder", "pos_embed_rope_rescale_coords"): "decoder_rope_rescale_coords",
     }
     _YAML_OPTIONAL = {"vision_init_values", "vision_use_qk_norm", "text_ls_init_value", "decoder_init_values", "decoder_use_qk_norm",
-                      "init_logit_scale", "init_logit_bias", "nonscalar_logit_scale"}
+                      "init_logit_scale", "init_logit_bias", "nonscalar_logit_scale"} | set(ROPE_AUG_KEYS)
 
     @classmethod
     def from_vtp_yaml(cls, yaml_path: str) -> "VTPConfig":

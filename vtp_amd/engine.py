@@ -191,10 +191,12 @@ class ParamStore:
         for d0, d1 in runs:
             ops.prep_weights_range(self._desc_dev[d0:], d1 - d0, self._desc_tile0[d0], self._desc_tile0[d1] - self._desc_tile0[d0])
 
-    def mark_prepped(self):
-        """every compute copy is current (the trainer refreshed them bucket by bucket): LayerScale hooks + the version stamp"""
+    def mark_prepped(self, done=()):
+        """every compute copy is current (the trainer refreshed them bucket by bucket): the derived-weight hooks that did not ride
+        along with a bucket (`done`) + the version stamp"""
         for hook in getattr(self, "prep_hooks", ()):
-            hook()
+            if hook not in done:
+                hook()
         self._prepped_version = self.flat_p._version
 
     def ensure_fresh(self):
@@ -458,11 +460,15 @@ class Stack:
 
     def _rope_plan(self, ws: Workspace, segs, prefix_tokens: int, M: int):
         """(rope_pos int32 [M], sin, cos) for the fused qkv + RoPE epilogue: rope_pos[m] = row of the concatenated per-segment
-        tables that rotates token row m, -1 for prefix (cls) rows.  Built once per workspace (static segment structure)."""
+        tables that rotates token row m, -1 for prefix (cls) rows.  Built once per workspace (static segment structure).  Under
+        train-time RoPE augmentation the segments carry RopeAugTabs: sin / cos are then the static per-block buffers [depth, P, 64]
+        themselves (refreshed in place every step; block i uses [i]), not a concatenated copy."""
         if self.style != "vit" or all(rp is None for _, _, rp in segs) or (2 * self.D) % 128 or self.qk_norm:
             return None  # (with QK normalisation the rotation follows the norm: it cannot ride in the projection's epilogue)
         hit = getattr(ws, "_rope_plan", None)
-        key = tuple((b, n, None if rp is None else rp[0].data_ptr()) for b, n, rp in segs) + (prefix_tokens,)
+        aug = [rp for _, _, rp in segs if isinstance(rp, RopeAugTabs)]
+        key = tuple((b, n, None if rp is None else (rp.sin_all.data_ptr(), rp.off) if isinstance(rp, RopeAugTabs) else rp[0].data_ptr())
+                    for b, n, rp in segs) + (prefix_tokens,)
         if hit is not None and hit[0] == key:
             return hit[1]
         pos, tabs_s, tabs_c, base = [], [], [], 0
@@ -470,18 +476,30 @@ class Stack:
             if rp is None:
                 pos.append(torch.full((Bs * Ns,), -1, dtype=torch.int32))
                 continue
-            hw = rp[0].shape[0]
+            hw = _rope_hw(rp)
             assert Ns - prefix_tokens == hw, (Ns, prefix_tokens, hw)
+            if aug:  # rows of the shared per-block buffers: the item's offset there
+                assert isinstance(rp, RopeAugTabs) and rp.sin_all is aug[0].sin_all, "augmented and plain RoPE tables cannot be mixed in one pass"
+                base = rp.off
             one = torch.cat([torch.full((prefix_tokens,), -1, dtype=torch.int32), torch.arange(hw, dtype=torch.int32) + base])
             pos.append(one.repeat(Bs))
-            tabs_s.append(rp[0])
-            tabs_c.append(rp[1])
-            base += hw
+            if not aug:
+                tabs_s.append(rp[0])
+                tabs_c.append(rp[1])
+                base += hw
         dev = self.store.device
-        plan = (torch.cat(pos).to(dev), torch.cat(tabs_s).contiguous(), torch.cat(tabs_c).contiguous())
+        if aug:
+            plan = (torch.cat(pos).to(dev), aug[0].sin_all, aug[0].cos_all)
+        else:
+            plan = (torch.cat(pos).to(dev), torch.cat(tabs_s).contiguous(), torch.cat(tabs_c).contiguous())
         assert plan[0].numel() == M
         ws._rope_plan = (key, plan)
         return plan
+
+    @staticmethod
+    def _plan_tabs(plan, i: int):
+        """sin / cos operands of the fused epilogue for block i"""
+        return (plan[1][i], plan[2][i]) if plan[1].ndim == 3 else (plan[1], plan[2])
 
     # ------------------------------------------------------------------------------------------------ stochastic depth
     # block.py:20-118 (get_branges_scales) and :207-289: in training with drop_ratio > 0 every residual branch of every block runs
@@ -583,13 +601,15 @@ class Stack:
             self._gather(x, segs, csegs, i, 0, xs1, None, 1.0)
             ops.norm_fwd(xs1, b.n1w, b.n1b, xn1, st1, Mc, D, self.eps, self.kind)
             if rope_plan is not None:
-                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, Mc, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+                ps, pc = self._plan_tabs(rope_plan, i)
+                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, Mc, 3 * D, D, rope_plan[0], ps, pc, 2 * D)
             else:
                 ops.gemm_nt(xn1, b.qkv.w, qkv, M=Mc, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
             for r0, Bs, Ns, rp in self._rows(csegs):
                 q_s = qkv[r0:r0 + Bs * Ns]
                 if rp is not None and rope_plan is None:
-                    ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
+                    rs, rc = rope_at(rp, i)
+                    ops.rope_qk(q_s, rs, rc, Bs, Ns, heads, prefix_tokens)
                 ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r0 + Bs * Ns], lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D,
                              Ns * D, D, scale, self.causal)
             ops.gemm_nt(o, b.proj.w, delta, M=Mc, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, epi=EPI_F32)
@@ -668,7 +688,7 @@ class Stack:
                 q_s, dq_s = qkv[r0:r1], dqkv[r0:r1]
                 ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
                              dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
-                             rope=rp, rope_prefix=prefix_tokens)
+                             rope=None if rp is None else rope_at(rp, i), rope_prefix=prefix_tokens)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, Mc, dxn)
             ops.norm_bwd(dxn, xs1, b.n1w, st1, gdy, dxc, None, b.gn1w, b.gn1b, Mc, D, self.kind)
             self._scatter(dxc, dy, segs, csegs, i, 0, 1.0, accumulate=False)
@@ -690,8 +710,9 @@ class Stack:
         images and the global crops of a list forward: one attention launch instead of two, a better last round of workgroups)."""
         out = []
         for r0, B, N, rope in Stack._rows(segs):
-            if out and out[-1][2] == N and (out[-1][3] is rope or (out[-1][3] is not None and rope is not None
-                                                                 and out[-1][3][0] is rope[0] and out[-1][3][1] is rope[1])):
+            same = out and (out[-1][3] is rope or (isinstance(out[-1][3], tuple) and isinstance(rope, tuple)
+                                                   and out[-1][3][0] is rope[0] and out[-1][3][1] is rope[1]))
+            if out and out[-1][2] == N and same:  # (RopeAugTabs of different items never merge: each item has its own draws)
                 out[-1] = (out[-1][0], out[-1][1] + B, N, rope)
             else:
                 out.append((r0, B, N, rope))
@@ -730,7 +751,8 @@ class Stack:
 
             ops.norm_fwd(x, b.n1w, b.n1b, xn1, st1, M, D, self.eps, self.kind)
             if rope_plan is not None:  # apply_rope rides in the epilogue of the qkv projection (all segments, one launch)
-                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, M, 3 * D, D, rope_plan[0], rope_plan[1], rope_plan[2], 2 * D)
+                ps, pc = self._plan_tabs(rope_plan, i)
+                ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, M, 3 * D, D, rope_plan[0], ps, pc, 2 * D)
             elif b.qn_w is not None:  # projection -> QK norm (pre-norm values and 1/rms kept for the backward) -> RoPE below
                 qkv_pre = ws.get(t + "qkv_pre", (M, 3 * D), BF)
                 qinv = ws.get(t + "qinv", (M, 2 * heads), F32)
@@ -741,7 +763,8 @@ class Stack:
             for r0, Bs, Ns, rp in self._attn_rows(segs):
                 q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
                 if rp is not None and rope_plan is None:
-                    ops.rope_qk(q_s, rp[0], rp[1], Bs, Ns, heads, prefix_tokens)
+                    rs, rc = rope_at(rp, i)
+                    ops.rope_qk(q_s, rs, rc, Bs, Ns, heads, prefix_tokens)
                 ops.attn_fwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o_s, lse[r0 * heads:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D,
                              scale, self.causal)
             ops.gemm_nt(o, b.proj.w, xmid, M=M, N=D, K=D, bias=b.proj.bias, gamma=b.ls1, resid=x, epi=EPI_F32)
@@ -904,7 +927,7 @@ class Stack:
                 # dq / dk come back as gradients w.r.t. the un-rotated q, k (inverse RoPE fused into the attention backward)
                 ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
                              dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
-                             rope=rp, rope_prefix=prefix_tokens)
+                             rope=None if rp is None else rope_at(rp, i), rope_prefix=prefix_tokens)
             if b.qn_w is not None:  # gradient w.r.t. the normalised q, k -> w.r.t. the projection output (in place), + dw
                 ops.qk_norm_bwd(dqkv, ws.get(f"{i}.qkv_pre", (M, 3 * D), BF), ws.get(f"{i}.qinv", (M, 2 * heads), F32), b.qn_w, b.kn_w,
                                 b.g_qn, b.g_kn, M, D)
@@ -940,23 +963,143 @@ class Stack:
 _ROPE_CACHE: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 
+def _rope_host(per: torch.Tensor, H: int, W: int, aug=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(sin, cos) bf16 [H*W, 64] on the host, op for op RopePositionEmbedding.forward (embeddings.py:131-180) in the dtype of `per`.
+    aug = {"shift": [2] | None, "jitter": [2] | None, "rescale": [1] | None}: the train-time coordinate augmentations (:155-171) with
+    GIVEN draws (shift added per axis; jitter -- already exp() of the log-uniform draw -- multiplied per axis; rescale multiplied)."""
+    dd = {"dtype": per.dtype}
+    ch = torch.arange(0.5, H, **dd) / H
+    cw = torch.arange(0.5, W, **dd) / W
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
+    coords = 2.0 * coords - 1.0
+    if aug is not None:
+        if aug.get("shift") is not None:
+            coords += aug["shift"][None, :]
+        if aug.get("jitter") is not None:
+            coords *= aug["jitter"][None, :]
+        if aug.get("rescale") is not None:
+            coords *= aug["rescale"]
+    ang = 2 * math.pi * coords[:, :, None] / per[None, None, :]
+    ang = ang.flatten(1, 2).tile(2)
+    return torch.sin(ang).to(torch.bfloat16).contiguous(), torch.cos(ang).to(torch.bfloat16).contiguous()
+
+
 def rope_tables(periods: torch.Tensor, H: int, W: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     per = periods.detach().to("cpu")
     key = (H, W, str(device), per.dtype, tuple(per.float().tolist()))
     hit = _ROPE_CACHE.get(key)
     if hit is not None:
         return hit
-    dd = {"dtype": per.dtype}
-    ch = torch.arange(0.5, H, **dd) / H
-    cw = torch.arange(0.5, W, **dd) / W
-    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
-    coords = 2.0 * coords - 1.0
-    ang = 2 * math.pi * coords[:, :, None] / per[None, None, :]
-    ang = ang.flatten(1, 2).tile(2)
-    sin = torch.sin(ang).to(torch.bfloat16).contiguous().to(device)
-    cos = torch.cos(ang).to(torch.bfloat16).contiguous().to(device)
+    sin, cos = _rope_host(per, H, W)
+    sin, cos = sin.to(device), cos.to(device)
     _ROPE_CACHE[key] = (sin, cos)
     return sin, cos
+
+
+class RopeAugTabs:
+    """RoPE tables of ONE list item under train-time augmentation: rows [off, off + hw) of the static per-block buffers
+    sin_all / cos_all bf16 [depth, P, 64] (P = patch tokens of all items).  The trunk evaluates rope_embed inside its block loop
+    (vision_transformer.py:228-233), so every block rotates with its own draw: Stack asks at(i) for block i's tables."""
+    __slots__ = ("sin_all", "cos_all", "off", "hw")
+
+    def __init__(self, sin_all, cos_all, off, hw):
+        self.sin_all, self.cos_all, self.off, self.hw = sin_all, cos_all, off, hw
+
+    def at(self, i: int):
+        return self.sin_all[i, self.off:self.off + self.hw], self.cos_all[i, self.off:self.off + self.hw]
+
+
+def rope_at(rp, i: int):
+    """(sin, cos) [hw, 64] of block i: per-block tables under augmentation, the shared pair otherwise"""
+    return rp.at(i) if isinstance(rp, RopeAugTabs) else rp
+
+
+def _rope_hw(rp) -> int:
+    return rp.hw if isinstance(rp, RopeAugTabs) else rp[0].shape[0]
+
+
+class RopeAugmenter:
+    """Train-time RoPE coordinate augmentations (RopePositionEmbedding shift / jitter / rescale, embeddings.py:155-171; constructor
+    arguments pos_embed_rope_*_coords of the ViT classes, reachable through the legacy YAML's vision_encoder / pixel_decoder sections):
+    host-side draws in the rope dtype, tables built with the reference's op order, uploaded into STATIC device buffers that are only ever
+    refreshed in place (captured hipGraph segments bake their addresses).  per_block: one draw per block and list item (trunk) or one
+    per forward (pixel decoder, pixel_decoder.py:144).  An eager forward refreshes its buffer itself; under stream capture nothing
+    is drawn -- the trainer calls refresh_all() before every replay."""
+
+    def __init__(self, periods: torch.Tensor, depth: int, per_block: bool, shift, jitter, rescale, seed: int = 0):
+        self.per, self.depth, self.per_block = periods.detach().to("cpu"), depth, per_block
+        self.cfg = (shift, jitter, rescale)
+        self.gen = torch.Generator().manual_seed(int(seed))
+        self.records: Dict[tuple, dict] = {}
+        self.last_draws = None  # [[draw dict per item] per block] of the latest refresh (tests replay them into the oracle)
+
+    @property
+    def active(self) -> bool:
+        return any(v is not None for v in self.cfg)
+
+    def _draw(self):
+        import numpy as np
+        shift, jitter, rescale = self.cfg
+        dd = {"dtype": self.per.dtype}
+        d = {"shift": None, "jitter": None, "rescale": None}
+        if shift is not None:
+            d["shift"] = torch.empty(2, **dd).uniform_(-shift, shift, generator=self.gen)
+        if jitter is not None:
+            jm = float(np.log(jitter))
+            d["jitter"] = torch.empty(2, **dd).uniform_(-jm, jm, generator=self.gen).exp()
+        if rescale is not None:
+            rm = float(np.log(rescale))
+            d["rescale"] = torch.empty(1, **dd).uniform_(-rm, rm, generator=self.gen).exp()
+        return d
+
+    def record(self, key, hws, device):
+        """static buffers for a forward whose list items have (h, w) = hws"""
+        rec = self.records.get(key)
+        if rec is None:
+            P = sum(h * w for h, w in hws)
+            nb = self.depth if self.per_block else 1
+            rec = dict(hws=list(hws), sin=torch.zeros(nb, P, 64, dtype=torch.bfloat16, device=device),
+                       cos=torch.zeros(nb, P, 64, dtype=torch.bfloat16, device=device),
+                       host=torch.zeros(2, nb, P, 64, dtype=torch.bfloat16).pin_memory(), event=None, fresh=False)
+            self.records[key] = rec
+        return rec
+
+    def refresh(self, rec):
+        """new draws -> host tables -> one non-blocking upload per table"""
+        if rec["event"] is not None:
+            rec["event"].synchronize()  # the pinned staging rows are rewritten only after the previous upload has executed
+        nb = rec["sin"].shape[0]
+        draws = []
+        for i in range(nb):
+            row, off = [], 0
+            for h, w in rec["hws"]:
+                d = self._draw()
+                sin, cos = _rope_host(self.per, h, w, d)
+                rec["host"][0, i, off:off + h * w].copy_(sin)
+                rec["host"][1, i, off:off + h * w].copy_(cos)
+                off += h * w
+                row.append(d)
+            draws.append(row)
+        rec["sin"].copy_(rec["host"][0], non_blocking=True)
+        rec["cos"].copy_(rec["host"][1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        rec["event"], rec["fresh"] = ev, True
+        self.last_draws = draws
+
+    def tables(self, key, hws, device):
+        """the record of this forward, refreshed unless the stream is being captured (then the trainer refreshes before each replay)"""
+        rec = self.record(key, hws, device)
+        if torch.cuda.is_current_stream_capturing():
+            if not rec["fresh"]:
+                raise RuntimeError("RoPE augmentation tables must exist before stream capture (run the step eagerly once)")
+        else:
+            self.refresh(rec)
+        return rec
+
+    def refresh_all(self):
+        for rec in self.records.values():
+            self.refresh(rec)
 
 
 # =====================================================================================================================
@@ -979,19 +1122,23 @@ class TrunkEngine:
         self.bott = store.lin(self.prefix + "feature_bottleneck.weight", None, self.bott_dim, self.D) \
             if store.has(self.prefix + "feature_bottleneck.weight") else None
         self.ws: Dict[tuple, Workspace] = {}
+        # train-time RoPE coordinate augmentations (embeddings.py:155-171): one draw per block and list item
+        self.rope_aug = RopeAugmenter(self.periods, self.depth, True, getattr(cfg, "vision_rope_shift_coords", None),
+                                      getattr(cfg, "vision_rope_jitter_coords", None), getattr(cfg, "vision_rope_rescale_coords", None),
+                                      seed=1 if prefix == "trunk." else 2)
 
     def workspace(self, key) -> Workspace:
         if key not in self.ws:
             self.ws[key] = Workspace(self.store.device)
         return self.ws[key]
 
-    def forward(self, img: torch.Tensor, train: bool, masks: Optional[torch.Tensor] = None, tag: str = ""):
+    def forward(self, img: torch.Tensor, train: bool, masks: Optional[torch.Tensor] = None, tag: str = "", rope_aug: Optional[bool] = None):
         """img f32 [B,3,H,W] -> final-norm tokens xnf bf16 [B*N, D] (N = 1 + hw).  masks: uint8 [B, hw] (1 = replace the
         patch embedding by mask_token, vision_transformer.py:194-196).  `tag` separates the buffers of passes that are in
         flight at the same time with the same shape; self.ctx() returns the handle backward() needs for such passes."""
-        return self.forward_list([(img, masks)], train, tag)
+        return self.forward_list([(img, masks)], train, tag, rope_aug=rope_aug)
 
-    def forward_list(self, items, train: bool, tag: str = ""):
+    def forward_list(self, items, train: bool, tag: str = "", rope_aug: Optional[bool] = None):
         """items = [(img f32 [B_i,3,H_i,W_i], masks_i or None)]: the reference's list forward (forward_features_list,
         vision_transformer.py:221-258): batches of different resolution go through the blocks as ONE row-concatenated
         token buffer (one GEMM / norm launch per layer for all of them, attention + RoPE per segment).  Returns xnf bf16
@@ -1010,6 +1157,14 @@ class TrunkEngine:
             p0 += B * sg.hw
         M, P = r0, p0
         ws = self.workspace((tuple((g.B, g.h, g.w) for g in segs), tag))
+        # rope_aug: None = follow `train` (RopePositionEmbedding augments when its module is in training mode); the EMA teacher's pass
+        # stores nothing for a backward (train=False) but belongs to a training step: its caller passes rope_aug=True
+        if self.rope_aug.active and (train if rope_aug is None else rope_aug):
+            rec = self.rope_aug.tables((tuple((g.B, g.h, g.w) for g in segs), tag), [(g.h, g.w) for g in segs], st.device)
+            off = 0
+            for g in segs:
+                g.rope = RopeAugTabs(rec["sin"], rec["cos"], off, g.hw)
+                off += g.hw
         patches = ws.get("patches", (P, 768), BF)
         x0 = ws.get("x0", (M, D), F32)
         for g in segs:
@@ -1131,6 +1286,9 @@ class DecoderEngine:
                            ffn=cfg.decoder_ffn_layer)
         self.pout = store.lin("pixel_decoder.proj_out.weight", "pixel_decoder.proj_out.bias", 768, self.D)
         self.ws: Dict[tuple, Workspace] = {}
+        # train-time RoPE augmentations: the decoder evaluates rope_embed ONCE per forward (pixel_decoder.py:144)
+        self.rope_aug = RopeAugmenter(self.periods, self.depth, False, getattr(cfg, "decoder_rope_shift_coords", None),
+                                      getattr(cfg, "decoder_rope_jitter_coords", None), getattr(cfg, "decoder_rope_rescale_coords", None), seed=3)
 
     def workspace(self, B, h, w) -> Workspace:
         key = (B, h, w)
@@ -1146,6 +1304,9 @@ class DecoderEngine:
         x0 = ws.get("x0", (M, D), F32)
         ops.gemm_nt(lat, self.pin.w, x0, M=M, N=D, K=self.cin, bias=self.pin.bias, epi=EPI_F32)
         rope = rope_tables(self.periods, h, w, st.device)
+        if train and self.rope_aug.active:
+            rec = self.rope_aug.tables((B, h, w), [(h, w)], st.device)
+            rope = (rec["sin"][0], rec["cos"][0])
         dropped = train and self.stack.drop_plan is not None
         if dropped:
             xl = self.stack.forward_drop(ws, x0, [(B, h * w, rope)], 0)

@@ -36,6 +36,11 @@ class DinoHeadEngine:
         if not hasattr(store, "prep_hooks"):
             store.prep_hooks = []
         store.prep_hooks.append(self.prep)
+        # what the hook reads: the trainer's optimizer lane runs it right behind the bucket update that covers these ranges (beside the
+        # backward) instead of in the serial tail of the step
+        ov, kv = store.offsets[prefix + "last_layer.weight_v"]
+        og, kg = store.offsets[prefix + "last_layer.weight_g"]
+        store.__dict__.setdefault("hook_deps", {})[self.prep] = [(ov, ov + kv), (og, og + kg)]
         self.ws: Dict[tuple, Workspace] = {}
 
     def prep(self):

@@ -567,7 +567,7 @@ class VTPTrainer:
         yield ends a hipGraph segment: nothing forked may be left open there); what is still queued after the last event runs on
         the main stream in the optimizer leg of the body."""
         self._reduced_ranges = []
-        self._opt_queue, self._opt_done = [], []
+        self._opt_queue, self._opt_done, self._hooks_done = [], [], set()
         self._opt_ema = ssl is not None
         lag = 2 if self.collectives else 1
         for ev in self._step_body(images, text, ssl, rec_images):
@@ -615,6 +615,13 @@ class VTPTrainer:
             ops.adamw_ema_dev(st.flat_p[a:b], st.flat_g[a:b], self.m[a:b], self.v[a:b], None if tl is None else st.flat_p[tl:tl + b - a],
                               b - a, self.hyper, None if self.nodecay4 is None else self.nodecay4[a // 4:b // 4])
         st.prep_runs(runs)
+        # derived weights that depend only on what this bucket updated (the DINO heads' weight-normed last layers, student and -- through
+        # the fused EMA -- teacher): re-derived here, beside the backward, not in the serial tail
+        touched = [(a, b) for a, b, _ in pieces] + [(tl, tl + b - a) for a, b, tl in pieces if tl is not None]
+        for hook, deps in getattr(st, "hook_deps", {}).items():
+            if hook not in self._hooks_done and all(any(a <= lo and hi <= b for a, b in touched) for lo, hi in deps):
+                hook()
+                self._hooks_done.add(hook)
         self._opt_done += [(a, b) for a, b, _ in pieces]
 
     def _opt_launch(self, keys):
@@ -845,7 +852,7 @@ class VTPTrainer:
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         if self.overlap_opt:  # EMA and the weight refresh rode along bucket by bucket
-            st.mark_prepped()
+            st.mark_prepped(self._hooks_done)
             return
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
             from .vtp import _range
@@ -1122,6 +1129,11 @@ class VTPTrainer:
             plan = (static_img, static_txt, static_ssl, segs, static_rec)
             self._graphs[key] = plan
         static_img, static_txt, static_ssl, segs, static_rec = plan
+        # train-time RoPE augmentations: fresh draws into the static table buffers the captured segments read (an eager step
+        # draws inside its forward passes; under capture nothing can be drawn)
+        for eng in (self.trunk, self.decoder, getattr(self.model, "_t_trunk", None)):
+            if eng is not None and eng.rope_aug.active:
+                eng.rope_aug.refresh_all()
         static_img.copy_(images)
         if rec_images is not None:
             static_rec.copy_(rec_images)

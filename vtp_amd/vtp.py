@@ -275,7 +275,7 @@ def ssl_forward(model: "VTP", global_crops, local_crops, masks_u8, plan, dev_pla
     Xt = ws.get("Xt", (Tt, D), BF)
 
     def teacher():
-        xnf_t = model._t_trunk.forward(global_crops, train=False, tag="teacher")
+        xnf_t = model._t_trunk.forward(global_crops, train=False, tag="teacher", rope_aug=train)  # (teacher_trunk is in training mode too)
         ops.gather_token_rows(xnf_t, idx["teacher_src"], Xt, Tt, D)
         return model._t_head.forward(Xt, Tt, tag="teacher")[0]
 
