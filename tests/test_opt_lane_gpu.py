@@ -99,7 +99,9 @@ def test_lane_matches_serial_optimizer_leg(sslg, use_graphs):
     for name, a, b, nz in zip(("params (student + teacher)", "exp_avg", "exp_avg_sq", "bf16 copies"), res["lane"], res["serial"], noise):
         e = relF(a, b)
         print(f"optimizer lane vs serial leg ({'graphs' if use_graphs else 'eager'}) {name}: rel {e:.2e} (serial vs serial {nz:.2e})")
-        assert e <= max(3 * nz, 2e-6), name
+        # floor: the run-to-run level of the eager step (fp32 atomics of the bias-gradient sums reorder with the timing: moments 4e-6,
+        # a bf16 weight copy flips an ulp at 5e-6); a graph replay happens to repeat itself to 1e-8, which is not the lane's reference
+        assert e <= max(3 * nz, 2e-5), name
 
 
 def test_lane_rec_only_and_rec_clip_steps(sslg):

@@ -109,4 +109,5 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+
 }  // namespace vtp

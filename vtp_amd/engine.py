@@ -264,7 +264,8 @@ class Overlap:
 
     def _side(self):
         if self._lane not in self._sides:
-            self._sides[self._lane] = torch.cuda.Stream()
+            # VTP_SIDE_PRIO (diagnostics): HIP stream priority of the side streams (0 = default; > 0 lower, < 0 higher where supported)
+            self._sides[self._lane] = torch.cuda.Stream(priority=int(os.environ.get("VTP_SIDE_PRIO", "0")))
         return self._sides[self._lane]
 
     def fork(self):
