@@ -264,8 +264,7 @@ class Overlap:
 
     def _side(self):
         if self._lane not in self._sides:
-            # VTP_SIDE_PRIO (diagnostics): HIP stream priority of the side streams (0 = default; > 0 lower, < 0 higher where supported)
-            self._sides[self._lane] = torch.cuda.Stream(priority=int(os.environ.get("VTP_SIDE_PRIO", "0")))
+            self._sides[self._lane] = torch.cuda.Stream()
         return self._sides[self._lane]
 
     def fork(self):

@@ -631,7 +631,7 @@ class VTPTrainer:
             return self._opt_update(keys)
         main = torch.cuda.current_stream()
         if self._opt_stream is None:
-            self._opt_stream = torch.cuda.Stream(priority=int(os.environ.get("VTP_LANE_PRIO", "0")))
+            self._opt_stream = torch.cuda.Stream()
         self._opt_stream.wait_stream(main)
         with torch.cuda.stream(self._opt_stream):
             self._opt_update(keys)
