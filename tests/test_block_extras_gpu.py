@@ -206,6 +206,56 @@ def test_stochastic_depth_with_mlp_ffn_vs_oracle():
         assert abs(a - b) < 2e-3 * abs(a)
 
 
+def test_stochastic_depth_with_qk_norm_vs_oracle():
+    """QK normalisation (attention.py:67-68,119-120) inside the sample-drop branch (block.py:207-289) -- the combination rounds 2-4 left
+    out: projection -> per-head RMSNorm of q, k -> RoPE on the kept images, and its backward incl. the q / k norm weights"""
+    from oracle import vtp_oracle as O
+    from vtp_amd import VTPTrainer
+    m, sd = _model(None, vision_use_qk_norm=True, decoder_use_qk_norm=True)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "q_norm" in n or "k_norm" in n:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    B = 5
+    img = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    tr = VTPTrainer(m, lr=0.0, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=6)
+    loss = tr.step_rec(img.to(DEV))
+    torch.cuda.synchronize()
+
+    def plan_of(stack):
+        p = stack.last_drop_plan
+        keep, alpha = p["keeps"][0], p["scales"][0]
+        idx = p["idx_dev"].cpu().long().view(stack.depth, 2, keep)
+        return [(idx[i, 0], alpha, idx[i, 1], alpha) for i in range(stack.depth)]
+
+    d_tr, d_dec = plan_of(tr.trunk.stack), plan_of(tr.decoder.stack)
+
+    def ref_loss(s_):
+        out = O.trunk_forward(s_, img, 2, use_bottleneck=True, drop=d_tr)
+        return O.l1_loss(O.decoder_forward(s_, out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, drop=d_dec), img)
+
+    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    loss_ref = ref_loss(ref)
+    loss_ref.backward()
+    ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        l16 = ref_loss(ref16)
+    l16.backward()
+    print(f"stochastic depth with QK normalisation: loss ours {float(loss):.5f} oracle {float(loss_ref):.5f}")
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+    _compare_grads(m, ref, ["trunk.blocks.0.attn.q_norm.weight", "trunk.blocks.1.attn.k_norm.weight", "pixel_decoder.blocks.0.attn.q_norm.weight",
+                            "trunk.blocks.0.attn.qkv.weight", "trunk.blocks.2.attn.qkv.bias", "trunk.blocks.1.mlp.w3.weight",
+                            "pixel_decoder.blocks.1.attn.qkv.weight", "trunk.patch_embed.proj.weight"], 3e-2, ref16)
+    res = []
+    for use_graphs in (False, True):
+        m2, _ = _model(None, vision_use_qk_norm=True, decoder_use_qk_norm=True)
+        t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, drop_rate=0.4, decoder_drop_rate=0.4, drop_seed=9, use_graphs=use_graphs)
+        res.append([float(t2.step_rec(img.to(DEV) + 0.01 * i)) for i in range(3)])
+    for a, b in zip(*res):
+        assert abs(a - b) < 2e-3 * abs(a)
+
+
 def test_rope_train_time_augmentations_vs_oracle():
     """RopePositionEmbedding shift / jitter / rescale (embeddings.py:155-171; `pos_embed_rope_*_coords` of the ViT classes, reachable
     through the legacy YAML): in training the trunk draws new coordinates per BLOCK (rope_embed sits inside its block loop,

@@ -106,7 +106,8 @@ _LARGE24 = dict(vision_embed_dim=1024, vision_depth=24, vision_num_heads=16, dec
                 decoder_num_heads=16, text_embed_dim=128, text_depth=1, text_num_heads=2, text_vocab_size=64, text_context_length=8)
 
 
-@pytest.mark.parametrize("name,cfg_kw,heads,B,res", [("4-block D=192", _TINY4, 3, 8, 64), ("VTP-L 24-block (config 5)", _LARGE24, 16, 2, 256)])
+@pytest.mark.parametrize("name,cfg_kw,heads,B,res", [("4-block D=192", _TINY4, 3, 8, 64), ("VTP-L 24-block (config 5)", _LARGE24, 16, 2, 256),
+                                                     ("4-block D=192 with QK normalisation", dict(_TINY4, vision_use_qk_norm=True, decoder_use_qk_norm=True), 3, 8, 64)])
 def test_fp8_encode_decode_vs_e4m3_simulated_oracle(name, cfg_kw, heads, B, res):
     """|ours_fp8 - oracle_fp32| <= 1.25 x |oracle_fp8sim - oracle_fp32| on the latents, on the decoder output for the SAME
     (reference) latents and end to end; E_ref = the larger of the simulated forward under CPU and CUDA bf16 autocast (the

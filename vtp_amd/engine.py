@@ -551,8 +551,6 @@ class Stack:
                 self.last_drop_plan = self.drop_plan  # introspection (tests replay the subsets of the step that just ran)
             self.drop_plan = None
             return
-        if self.qk_norm:
-            raise NotImplementedError("stochastic depth together with QK normalisation is not built (the sample-drop branch runs the plain attention path)")
         bufs = self.__dict__.setdefault("_drop_bufs", {})
         n = plan["idx"].numel()
         buf = bufs.get(n)
@@ -603,6 +601,11 @@ class Stack:
             if rope_plan is not None:
                 ps, pc = self._plan_tabs(rope_plan, i)
                 ops.gemm_qkv_rope(xn1, b.qkv.w, b.qkv.bias, qkv, Mc, 3 * D, D, rope_plan[0], ps, pc, 2 * D)
+            elif b.qn_w is not None:  # QK normalisation (attention.py:67-68,119-120) on the kept images: projection -> norm -> RoPE below
+                qkv_pre = ws.get(t + "qkv_pre", (Mc, 3 * D), BF)
+                qinv = ws.get(t + "qinv", (Mc, 2 * heads), F32)
+                ops.gemm_nt(xn1, b.qkv.w, qkv_pre, M=Mc, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
+                ops.qk_norm_fwd(qkv_pre, b.qn_w, b.kn_w, qkv, qinv, Mc, D)
             else:
                 ops.gemm_nt(xn1, b.qkv.w, qkv, M=Mc, N=3 * D, K=D, bias=b.qkv.bias, epi=EPI_BF16)
             for r0, Bs, Ns, rp in self._rows(csegs):
@@ -689,6 +692,9 @@ class Stack:
                 ops.attn_bwd(q_s, q_s[:, D:], q_s[:, 2 * D:], o[r0:r1], d_o[r0:r1], lse[r0 * heads:], delta[r0 * heads:], dq_s,
                              dq_s[:, D:], dq_s[:, 2 * D:], Bs, Ns, heads, Ns * 3 * D, 3 * D, Ns * D, D, scale, self.causal,
                              rope=None if rp is None else rope_at(rp, i), rope_prefix=prefix_tokens)
+            if b.qn_w is not None:
+                ops.qk_norm_bwd(dqkv, ws.get(f"{i}.d.qkv_pre", (Mc, 3 * D), BF), ws.get(f"{i}.d.qinv", (Mc, 2 * heads), F32), b.qn_w, b.kn_w,
+                                b.g_qn, b.g_kn, Mc, D)
             linear_bwd(ws, "qkv", b.qkv, dqkv, xn1, Mc, dxn)
             ops.norm_bwd(dxn, xs1, b.n1w, st1, gdy, dxc, None, b.gn1w, b.gn1b, Mc, D, self.kind)
             self._scatter(dxc, dy, segs, csegs, i, 0, 1.0, accumulate=False)
@@ -787,8 +793,8 @@ class Stack:
     # ---- fp8 (e4m3) inference forward: BASELINE config 5 (per-tensor scales: weights from their own amax, activations from a
     # calibration pass of the bf16 path over representative images)
     def fp8_begin_calibration(self):
-        if not self.swiglu or self.D % 16 or self.H % 16 or self.qk_norm or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
-            raise NotImplementedError("fp8 forward: ViT blocks with D, H multiples of 16, no LayerScale, no QK normalisation")
+        if not self.swiglu or self.D % 16 or self.H % 16 or any(b.ls1 is not None or b.ls2 is not None for b in self.blocks):
+            raise NotImplementedError("fp8 forward: SwiGLU ViT blocks with D, H multiples of 16, no LayerScale")
         dev = self.store.device
         self.fp8 = {"ready": False, "amax": torch.zeros(self.depth, 4, dtype=F32, device=dev)}
 
@@ -829,7 +835,12 @@ class Stack:
             w8, al, sc = f["w"][i], f["alpha"][i], f["act_scale"][i]
             xout = ws.get(f"xout{i & 1}", (M, D), F32)
             ops.norm_fwd_e4m3(x, b.n1w, b.n1b, a8, sc[0:1], None, M, D, self.eps, self.kind)  # norm + quantise in one pass
-            ops.gemm_nt_fp8(a8, w8[0], qkv, M=M, N=3 * D, K=D, alpha=al[0], bias=b.qkv.bias, epi=EPI_BF16, rope=rope_arg)
+            if b.qn_w is not None:  # QK normalisation (round 5): e4m3 projection -> bf16 pre-norm q, k -> RMSNorm(head_dim) -> RoPE below
+                qkv_pre = ws.get("f8.qkv_pre", (M, 3 * D), BF)
+                ops.gemm_nt_fp8(a8, w8[0], qkv_pre, M=M, N=3 * D, K=D, alpha=al[0], bias=b.qkv.bias, epi=EPI_BF16)
+                ops.qk_norm_fwd(qkv_pre, b.qn_w, b.kn_w, qkv, ws.get("f8.qinv", (M, 2 * heads), F32), M, D)
+            else:
+                ops.gemm_nt_fp8(a8, w8[0], qkv, M=M, N=3 * D, K=D, alpha=al[0], bias=b.qkv.bias, epi=EPI_BF16, rope=rope_arg)
             for r0, Bs, Ns, rp in self._attn_rows(segs):
                 q_s, o_s = qkv[r0:r0 + Bs * Ns], o[r0:r0 + Bs * Ns]
                 if rp is not None and rope_arg is None:
