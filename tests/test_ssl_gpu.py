@@ -73,6 +73,16 @@ def test_ssl_kernels_vs_torch():
     vr, gr = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
     wr = gr[:, None] * vr / vr.norm(dim=1, keepdim=True)
     assert torch.equal(weff, bf(wr.detach())) and torch.equal(weffT, weff.T)
+    # the tiled variant (C <= 256: transposed copy written in full lines, round 5) at the DINO head's shape and with a row tail
+    for K2, C2 in ((65536, 256), (1000, 256), (130, 200)):
+        v2 = torch.randn(K2, C2, device=DEV, generator=g) * 0.02
+        g2 = torch.rand(K2, device=DEV, generator=g) + 0.5
+        w2, w2T = torch.empty(K2, C2, dtype=torch.bfloat16, device=DEV), torch.full((C2, K2), 9.0, dtype=torch.bfloat16, device=DEV)
+        inv2 = torch.empty(K2, device=DEV)
+        o.weight_norm_prep(v2, g2, w2, w2T, inv2, K2, C2)
+        ref2 = g2[:, None] * v2 / v2.norm(dim=1, keepdim=True)
+        assert relF(w2, ref2) < 4e-3 and torch.equal(w2T, w2.T.contiguous()), (K2, C2)
+        assert relF(inv2, 1.0 / v2.norm(dim=1)) < 1e-6
     dW = torch.randn(K, C, device=DEV, generator=g)
     wr.backward(dW)
     dv, dg = torch.ones_like(v), torch.ones_like(gg)

@@ -64,6 +64,40 @@ __global__ __launch_bounds__(256) void weight_norm_prep_kernel(const float* __re
   if (lane == 0) inv_norm[k] = inv;
 }
 
+// The same for C <= 256 with the transposed copy written in full lines (round 5): a workgroup takes 64 prototype rows, keeps their
+// bf16 values in an LDS tile and writes W_eff^T as [c][64 consecutive k] row pieces (128 B per wave-instruction) -- the kernel above
+// scatters 2-byte elements 2 K bytes apart (152 us for the 65536 x 256 head of the benchmarked step against ~30 us of HBM time).
+// Same arithmetic per element (wave-sum of squares in the same lane order, rsqrt, one rounding): bit-identical outputs.
+__global__ __launch_bounds__(256) void weight_norm_prep_tiled_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                     bf16* __restrict__ weff, bf16* __restrict__ weffT,
+                                                                     float* __restrict__ inv_norm, int K, int C) {
+  __shared__ bf16 tile[64][256 + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 64;
+  for (int r = wave; r < 64; r += 4) {  // wave = one prototype row at a time, 16 rows per wave
+    const int k = k0 + r;
+    if (k >= K) break;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float x = v[(long)k * C + c];
+      s += x * x;
+    }
+    s = wave_sum(s);
+    const float inv = rsqrtf(s);
+    const float sc = g[k] * inv;
+    for (int c = lane; c < C; c += 64) {
+      const bf16 w = f2bf(v[(long)k * C + c] * sc);
+      weff[(long)k * C + c] = w;
+      tile[r][c] = w;
+    }
+    if (lane == 0) inv_norm[k] = inv;
+  }
+  __syncthreads();
+  const int k = k0 + lane;
+  if (k < K)
+    for (int c = wave; c < C; c += 4) weffT[(long)c * K + k] = tile[lane][c];
+}
+
 // dv += (g/||v||) * (dW - <dW, vhat> vhat) ; dg += <dW, vhat>        (vhat = v/||v||)
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ v,
                                                               const float* __restrict__ g, const float* __restrict__ inv_norm,
@@ -289,8 +323,12 @@ extern "C" int vtp_scatter_token_rows(const void* d_dst, const int* idx, void* d
 extern "C" int vtp_weight_norm_prep(const float* v, const float* g, void* weff, void* weffT, float* inv_norm, int K, int C,
                                     void* stream) {
   VTP_REQUIRE(v && g && weff && inv_norm && K > 0 && C > 0, "vtp_weight_norm_prep: bad argument");
-  hipLaunchKernelGGL(weight_norm_prep_kernel, dim3(cdiv(K, 4)), dim3(256), 0, (hipStream_t)stream, v, g, (bf16*)weff,
-                     (bf16*)weffT, inv_norm, K, C);
+  if (weffT && C <= 256)
+    hipLaunchKernelGGL(weight_norm_prep_tiled_kernel, dim3(cdiv(K, 64)), dim3(256), 0, (hipStream_t)stream, v, g, (bf16*)weff,
+                       (bf16*)weffT, inv_norm, K, C);
+  else
+    hipLaunchKernelGGL(weight_norm_prep_kernel, dim3(cdiv(K, 4)), dim3(256), 0, (hipStream_t)stream, v, g, (bf16*)weff,
+                       (bf16*)weffT, inv_norm, K, C);
   return check_launch("weight_norm_prep");
 }
 
