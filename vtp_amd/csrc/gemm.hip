@@ -364,17 +364,9 @@ bool gemm8p_combine_ready(hipStream_t s);
 int launch_gemm8h_nt(const GemmArgs& a, int epi, hipStream_t s);
 // gemm4w.hip: 256x256, one software-pipelined wave per SIMD (cfg 10; NT, one K slice, no A row remap)
 int launch_gemm4w_nt(const GemmArgs& a, int epi, hipStream_t s);
-// gemm4s.hip: EXPERIMENT (cfg 11, forced only): split accumulator set, epilogue inside the next tile's k loop
-int launch_gemm4s_nt(const GemmArgs& a, int epi, hipStream_t s);
 
 template <int EPI, bool TRANS>
 static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
-  if (cfg == 11) {
-    if constexpr (!TRANS && EPI == EPI_BF16) {
-      if (splits == 1) return launch_gemm4s_nt(a, EPI, s);
-    }
-    cfg = TRANS ? 5 : 8;
-  }
   if (cfg == 10) {
     if constexpr (!TRANS && (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_SWIGLU || EPI == EPI_GELU)) {
       if (splits == 1 && a.N % 256 == 0 && a.K % 128 == 0 && a.a_grp == 0 && a.conv_cin == 0 && !a.timing &&
