@@ -119,8 +119,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
       // the lane's bias values do not depend on the row block: ONE round of loads per tile (in front of the first block's
       // conversions) instead of one L2 round trip inside every block
-      constexpr bool HAS_BIAS = XMODE != 2;  // (the SwiGLU-backward instantiation is a dgrad: no bias, and no registers for one)
+      // XMODE 1 (apply_rope) keeps the rotation tables of a row block in registers across the block loop (below) and has no room for
+      // the bias values beside them: there the bias goes into the accumulators in a pre-pass (same two roundings per element)
+      constexpr bool HAS_BIAS = XMODE != 2;  // (the SwiGLU-backward instantiation is a dgrad: no bias, no registers for one)
       f32x4 bias_v[HAS_BIAS ? TN : 1][4];
+      if constexpr (XMODE == 77) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
+            const f32x4 b = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = acc[i][j][4 * q + e] * p.alpha;
+                acc[i][j][4 * q + e] = v + b[e];
+              }
+          }
+      }
       if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -145,13 +163,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
         }
       };
       if (x_swiglu) fetch_pre(0, sx1[0], sx2[0]);
+      // fused apply_rope, XMODE 1: the table rows of a block are two DEPENDENT loads (position of the row, then its cos / sin chunks), and
+      // issued behind the previous block's stores they also wait for those (one in-order vmcnt): three exposed round trips per 32-row
+      // block, 12 us of a 256 x 256 tile that computes for 20.  Here the positions of the wave tile's rows are loaded once (row k*64 + lane
+      // in lane `lane`, handed out by ds_bpermute), and the tables of block j + 1 are requested after block j's rotation has consumed
+      // its own, item by item, each BEFORE that item's store: older than it in the queue, in flight under the next block's conversions.
+      const bool rope_wave = XMODE == 1 && n0 + wn * WTN < p.rope_cols;  // wave-uniform: this wave's columns are q / k heads
+      int rpos[XMODE == 1 ? WTM / 64 : 1];
+      bf16x8 rcs[XMODE == 1 ? TPB : 1], rsn[XMODE == 1 ? TPB : 1];
+      int rps[XMODE == 1 ? TPB : 1];
+      auto fetch_tab = [&](int j, int t) {
+        {
+          const int row = j * 32 + (t * 64 + lane_t) / CPR;  // row of the wave tile this lane handles as item t of block j
+          const int pos = __shfl(rpos[(row >> 6) % (WTM / 64)], row & 63, 64);
+          rps[t] = pos;
+          const size_t off = (size_t)max(pos, 0) * 64 + (lane_t % CPR & 7) * 8;
+          rcs[t] = *(const bf16x8*)(p.rope_cos + off);
+          rsn[t] = *(const bf16x8*)(p.rope_sin + off);
+        }
+      };
+      if constexpr (XMODE == 1) {
+        static_assert(WTM % 64 == 0 && (64 % CPR) == 0, "rope position hand-out assumes 64-row groups");
+        if (rope_wave) {
+#pragma unroll
+          for (int k = 0; k < WTM / 64; ++k) {
+            const int m = m0 + wm * WTM + k * 64 + lane_t;
+            rpos[k] = m < p.M ? p.rope_pos[m] : -1;
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         if (x_swiglu && j + 1 < TM) fetch_pre(j + 1, sx1[(j + 1) & 1], sx2[(j + 1) & 1]);
         // (per row block again an opaque lane id: the LDS / global addressing of the four unrolled blocks is otherwise shared, lives
         // across the whole epilogue and spills -- with a drain of every load in flight behind each reload)
         int lane = lane_t, hi = lane_t >> 5, r = lane_t & 31;
-        if constexpr (XMODE == 2) {
+        if constexpr (XMODE == 2 || XMODE == 1) {
           asm volatile("" : "+v"(lane));
           hi = lane >> 5;
           r = lane & 31;
@@ -167,12 +214,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
             if constexpr (HAS_BIAS) v += bias_v[i][q];
             *(bf16x4*)(reg + r * RB + (((nl >> 3) ^ (r & (CPR - 1))) << 4) + hi * 8) = __builtin_convertvector(v, bf16x4);
           }
+        if constexpr (XMODE == 1) {
+          if (rope_wave) {  // per item: read back, rotate, request the item's tables of the NEXT block, store
+            if (j == 0) {  // (behind block 0's conversions: the tables take the registers its accumulators leave)
+#pragma unroll
+              for (int t = 0; t < TPB; ++t) fetch_tab(0, t);
+            }
+#pragma unroll
+            for (int t = 0; t < TPB; ++t) {
+              const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
+              bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
+              typedef __attribute__((ext_vector_type(4))) int i32x4;
+              const i32x4 vi = (i32x4)val;
+              i32x4 pi;
+#pragma unroll
+              for (int w = 0; w < 4; ++w) pi[w] = __shfl_xor(vi[w], 4, 64);
+              const bf16x8 prt = (bf16x8)pi;
+              const float sg = (lane & 4) ? 1.f : -1.f;
+              if (rps[t] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  val[e] = f2bf(bf2f(f2bf(bf2f(val[e]) * bf2f(rcs[t][e]))) + bf2f(f2bf(sg * bf2f(prt[e]) * bf2f(rsn[t][e]))));
+              }
+              if (j + 1 < TM) fetch_tab(j + 1, t);
+              __builtin_amdgcn_sched_barrier(0);
+              const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
+              if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n) = val;
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
           const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
           bf16x8 val = *(const bf16x8*)(reg + rr * RB + ((c ^ (rr & (CPR - 1))) << 4));
           const int m = m0 + wm * WTM + j * 32 + rr, n = n0 + wn * WTN + c * 8;
-          if (x_rope && n0 + wn * WTN < p.rope_cols) {  // wave-uniform: this wave's columns are q / k heads
+          if (XMODE < 0 && x_rope && n0 + wn * WTN < p.rope_cols) {  // wave-uniform: this wave's columns are q / k heads (run-time variant)
             // a head is 8 consecutive 16-B chunks of the row image: the partner element d +- 32 sits in chunk c ^ 4 = lane ^ 4.
             // out = x*cos + rot_half(x)*sin with the three eager-bf16 roundings of the reference (rope_qk_kernel, bit-identical)
             typedef __attribute__((ext_vector_type(4))) int i32x4;
