@@ -464,12 +464,18 @@ def main():
         trainer.bucketer.comm_bytes = 0
         host_t[:] = [0.0, 0.0, 0.0, 0.0]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step spread (one event record per step: free)
+        marks[0].record()
+        for i in range(steps):
             loss, closs = one_step(trainer, txt)
+            marks[i + 1].record()
         state["host_split_ms"] = [round(v * 1e3 / steps, 3) for v in host_t]
         state["host_ms_per_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 3)  # enqueue time: << ms_per_step unless host-bound
         sync()
         elapsed = time.perf_counter() - t0
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        state["per_step_ms"] = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
+        state["step_ms_spread"] = {"min": round(per[0], 3), "median": round(per[len(per) // 2], 3), "max": round(per[-1], 3)}
         if world > 1:
             state["comm"] = {**ROLL, "exposed_ms_per_step": round(trainer.comm_exposed_ms() / steps, 3),
                              "payload_mb_per_step": round(trainer.bucketer.comm_bytes / steps / 1e6, 1),
@@ -484,6 +490,10 @@ def main():
 
     model, lp, trainer, txt, launch, elapsed, loss, closs = measure(args.perceptual_weight, args.steps, args.warmup)
     state["host_ms_main"], state["host_split_main"] = state.get("host_ms_per_step"), state.get("host_split_ms")
+    state["spread_main"] = state.get("step_ms_spread")
+    state["per_step_main"] = state.get("per_step_ms")
+    if rank == 0:
+        print(f"[bench] per-step ms (HIP events on the main stream): {state.get('per_step_ms')}", file=sys.stderr, flush=True)
     state["comm_main"] = state.pop("comm", None)  # rank 0's main-stream waits (the second, LPIPS-on measurement overwrites "comm")
     ssl = None
     if do_ssl:  # the instrumented step below reuses the last drawn batch
@@ -699,7 +709,7 @@ def main():
                    "launch": launch, "global_batch": world * B, "per_gpu_batch": B, "resolution": res, "parallelism": f"dp{world}" + ("" if backend == "nccl" else f" ({backend} rehearsal, shared GPU)"),
                    "train_gflop_per_image": round(gflop_img, 1),
                    "reference_accounting_gflop_per_image": round(gflop_ref, 1)},
-        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "host_enqueue_ms_per_step": state.get("host_ms_main"), "host_split_ms": state.get("host_split_main"),
+        "loss": round(loss_val, 5), "clip_loss": round(closs_val, 5), "step_ms_spread": state.get("spread_main"), "host_enqueue_ms_per_step": state.get("host_ms_main"), "host_split_ms": state.get("host_split_main"),
         "host_split_legend": ["mask collate", "prepare_ssl work (index plan + pinned pack + H2D enqueue)", "step() enqueue",
                               "prepare_ssl back-pressure wait (host ahead of the GPU: idle, not work)"], "ssl": ssl_info, "lpips": lpips_info, "lpips_on": lpips_on, "separate_passes": separate,
         "comm": state.get("comm_main"),

@@ -352,6 +352,12 @@ class VTPTrainer:
         self._hyper_ring = None
         self.use_graphs = use_graphs
         self._graphs = {}
+        # VTP_SINGLE_GRAPH=1 (experiment, off by default): without collectives nothing has to run BETWEEN graph segments, so the whole
+        # step can be captured as ONE hipGraph with the optimizer lane left forked across the bucket events (joined once, in front of
+        # the optimizer leg).  A kernel trace shows ~27 us of idle GPU at each of the 13 segment boundaries of a step, but the step
+        # time does not move (same box, 30 steps: 46.45 / 46.74 ms with segments, 46.69 / 46.86 ms as one graph): the boundaries'
+        # idle time is slack of the side streams, not of the critical path
+        self.single_graph = (not self.collectives) and os.environ.get("VTP_SINGLE_GRAPH", "0") in ("1", "true", "on")
         if self.text is not None and (model.config.vision_clip_feat != "cls" or not model.config.vision_bottleneck_ae_only):
             self._clip_unsupported = ("the fused trainer implements the cls-token / un-bottlenecked CLIP image feature only "
                                       "(vision_clip_feat='cls', vision_bottleneck_ae_only=True); other settings train through "
@@ -570,8 +576,12 @@ class VTPTrainer:
         self._opt_queue, self._opt_done, self._hooks_done = [], [], set()
         self._opt_ema = ssl is not None
         lag = 2 if self.collectives else 1
+        # the lane is joined in front of every event when an event ends a graph segment / launches a collective; with one graph per
+        # step (or eager launches without collectives) only in front of the optimizer leg
+        lazy_join = not self.collectives and (self.single_graph or not self.use_graphs)
         for ev in self._step_body(images, text, ssl, rec_images):
-            self._opt_join()
+            if not lazy_join or callable(ev) or "FINAL" in ev:
+                self._opt_join()
             if callable(ev):
                 yield ev
                 continue
@@ -792,10 +802,14 @@ class VTPTrainer:
                 held.append("clip_head")
             else:
                 yield ["clip_head"]
-        # decoder backward; while the text stream is busy its first event is held back (a yield ends a graph segment, and every
-        # forked stream must be joined before that) so the text backward overlaps the decoder tail + its first blocks
+        # decoder backward; while the text stream is busy the decoder's bucket events are held back (a yield ends a graph segment /
+        # launches collectives, and every forked stream must be joined before that): the text backward (few-tile GEMMs, M = 77 B
+        # rows) runs beside the WHOLE decoder backward (M = 256 B rows), and both towers' buckets are announced together in front
+        # of the trunk backward, whose 20 ms hide their reductions / updates.  (Round 4 joined at the decoder's second event, i.e.
+        # after bucket_blocks blocks: the rest of the text backward then ran alone on a mostly empty chip -- measured same-box with
+        # bucket_blocks 3 -> 12: 686 -> 705 images/s, all of it from this join)
         dec_gen = self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
-        d_lat, seen = None, 0
+        d_lat = None
         while True:
             try:
                 ev = next(dec_gen)
@@ -803,12 +817,8 @@ class VTPTrainer:
                 d_lat = stop.value
                 break
             if held is not None:
-                if seen < 1:
-                    held += ev
-                    seen += 1
-                    continue
-                main.wait_stream(T)
-                ev, held = held + ev, None
+                held += ev
+                continue
             yield ev
         if held is not None:
             main.wait_stream(T)
@@ -1121,10 +1131,16 @@ class VTPTrainer:
                 ev = None
                 # thread_local capture mode: the RCCL watchdog thread keeps querying events while this thread captures
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    try:
-                        ev = next(gen)
-                    except StopIteration:
-                        done = True
+                    while True:
+                        try:
+                            ev = next(gen)
+                        except StopIteration:
+                            done = True
+                            break
+                        if not self.single_graph or callable(ev):
+                            break  # something runs between the segments: a collective, or the reductions of a bucket
+                        self._handle(ev)  # no collectives: bookkeeping only -- the capture goes on in the same graph
+                        ev = None
                 segs.append((g, ev))
             plan = (static_img, static_txt, static_ssl, segs, static_rec)
             self._graphs[key] = plan
