@@ -517,3 +517,31 @@ def test_generated_k_loops_are_up_to_date(tmp_path, monkeypatch):
     assert sum("v_mfma" in l for l in body) == 128 and sum("global_load_lds" in l for l in body) == 32 and sum("s_barrier" in l for l in body) == 4
     tn = gen.tn_body(True)
     assert sum("v_mfma" in l for l in tn) == 128 and sum("ds_read_b64_tr_b16" in l for l in tn) == 48 + 128 and sum("v_dot2" in l for l in tn) == 128
+
+
+def test_trace_gaps_union_and_gap_accounting(tmp_path, capsys, monkeypatch):
+    """tools/trace_gaps.py on a hand-made kernel trace: two streams whose kernels overlap, a 30-us and a 5-us hole per step; the marker
+    kernel delimits the steps, the union of the intervals (not their sum) is the busy time."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("trace_gaps", os.path.join(root, "tools", "trace_gaps.py"))
+    tg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg)
+    rows = ["Start_Timestamp,End_Timestamp,Kernel_Name"]
+    for s in range(5):  # 5 steps of 1000 us
+        t = 1_000_000 * s
+        rows += [f"{t},{t + 100_000},marker_kernel",                 # 0 .. 100
+                 f"{t + 50_000},{t + 400_000},gemm_a",                # 50 .. 400 (overlaps the marker)
+                 f"{t + 430_000},{t + 700_000},gemm_b",               # hole of 30 us in front
+                 f"{t + 600_000},{t + 900_000},side_kernel",          # overlaps gemm_b
+                 f"{t + 905_000},{t + 1_000_000},tail_kernel"]        # hole of 5 us in front
+    f = tmp_path / "k.csv"
+    f.write_text("\n".join(rows) + "\n")
+    monkeypatch.setattr(sys, "argv", ["trace_gaps.py", str(f), "--marker", "marker_kernel", "--skip", "1"])
+    detail, nsteps, wall = tg.main()
+    out = capsys.readouterr().out
+    assert nsteps == 3 and wall == 3_000_000
+    assert sorted(x for x, *_ in detail) == [5_000] * 3 + [30_000] * 3
+    assert "idle/step 0.035 ms" in out and "busy(union)/step 0.965 ms" in out
+    assert "sum of kernel durations/step 1.115 ms" in out  # 100 + 350 + 270 + 300 + 95 us: more than the wall time, streams overlap
+    assert "idle before gemm_b" in out
