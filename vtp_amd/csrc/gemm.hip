@@ -404,7 +404,11 @@ static int launch_gemm(const GemmArgs& a, int splits, int cfg, hipStream_t s) {
       case 1: return launch_cfg<128, 128, 2, 2, 3, EPI, false>(a, splits, s);
       case 2: return launch_cfg<256, 128, 4, 2, 2, EPI, false>(a, splits, s);
       case 3: return launch_cfg<256, 128, 4, 2, 3, EPI, false>(a, splits, s);
-      case 4: return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, splits, s);
+      case 4:
+        // the bf16 instantiation of the 256 x 256 ring tile spilled 462 VGPRs (the run-time RoPE / SwiGLU-backward extras on top of 256
+        // accumulator registers) and is only a fallback since the 8-phase kernel took these shapes: it is the 256 x 128 tile now
+        if constexpr (EPI == EPI_BF16) return launch_cfg<256, 128, 4, 2, 2, EPI, false>(a, splits, s);
+        else return launch_cfg<256, 256, 4, 2, 2, EPI, false>(a, splits, s);
       case 5: return launch_cfg<128, 128, 4, 2, 2, EPI, false>(a, splits, s);
       case 6: return launch_cfg<128, 128, 2, 2, 4, EPI, false>(a, splits, s);
       case 7: return launch_cfg<128, 64, 4, 1, 3, EPI, false>(a, splits, s);   // few-tile shapes: twice the workgroups
