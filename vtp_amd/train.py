@@ -339,6 +339,9 @@ class VTPTrainer:
         self._opt_stream = self._zero_stream = None
         self._opt_plans = {}
         self._opt_busy = self._zero_busy = False
+        # the SSL head's loss + backward on its own stream beside the decoder forward (one GPU / no collectives; VTP_HEAD_OVERLAP=0: in line)
+        self.head_overlap = os.environ.get("VTP_HEAD_OVERLAP", "1") not in ("0", "false", "off")
+        self._head_stream, self._head_keys = None, []
         self._works_prev = []  # (work, after) pairs of the previous bucket event's reductions (_handle)
         self.collectives = self.bucketer.active  # world > 1, or a one-rank group with force_collectives
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
@@ -443,6 +446,37 @@ class VTPTrainer:
         K, D = head.K, self.trunk.D
         out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
         self._zero_join()  # the gradient buffer was zeroed under the forward passes; the head backward below is its first writer
+        if not (self.head_overlap and not self.collectives and OVERLAP.enabled):
+            yield from self._ssl_tail(out, P)
+            return out
+        # HEAD STREAM (no collectives: the tail below yields nothing but its bucket key): teacher softmax / centring, DINO + iBOT
+        # cross-entropy, the head backward and the scatter into d_xnf -- 1.2 ms of mostly HBM-bound kernels, one at a time -- run on
+        # their own stream beside the decoder forward / text tower / CLIP loss (MFMA-bound, few tiles); joined in front of the trunk
+        # backward, where the head's bucket is announced (_step_body).  The head's weight gradients stay in line on that stream (a fork
+        # from an already forked stream breaks hipStreamEndCapture on ROCm 7.2); d_xnf is cleared HERE, on the main stream, because the
+        # CLIP head writes its cls rows into it while the head stream is still busy.
+        main = torch.cuda.current_stream()
+        self.trunk.d_xnf_buffer(out["ctx"]).zero_()
+        if self._head_stream is None:
+            self._head_stream = torch.cuda.Stream()
+        self._head_stream.wait_stream(main)
+        with torch.cuda.stream(self._head_stream), OVERLAP.lane(2):
+            was, OVERLAP.enabled = OVERLAP.enabled, False
+            try:
+                for ev in self._ssl_tail(out, P, zero_dxnf=False):
+                    if callable(ev):
+                        raise RuntimeError("head stream: the SSL tail asked for a collective")
+                    self._head_keys += ev
+            finally:
+                OVERLAP.enabled = was
+        return out
+
+    def _ssl_tail(self, out, P, zero_dxnf: bool = True):
+        """teacher targets, DINO + iBOT loss, head backward, scatter of the head's input gradient into the trunk's d_xnf rows (the
+        part of the SSL leg behind the forward passes); yields the collectives of the centring / Sinkhorn and the head's bucket key"""
+        model, st, head = self.model, self.store, self.ssl_head
+        dist = self.bucketer.dist
+        K, D = head.K, self.trunk.D
         Tt, Ts, Tm, B2, nl = out["Tt"], out["Ts"], out["Tm"], out["B2"], out["nl"]
         ws = out["ws"]
         t_logits, s_logits = out["teacher_logits"], out["student_logits"]
@@ -480,11 +514,11 @@ class VTPTrainer:
         yield ["dino_head"]
         ctx = out["ctx"]
         d_xnf = self.trunk.d_xnf_buffer(ctx)
-        d_xnf.zero_()
+        if zero_dxnf:
+            d_xnf.zero_()
         seg_g, seg_l = ctx.segs[-2], ctx.segs[-1]
         ops.scatter_token_rows(dX, P["dev"]["student_local_src"], d_xnf[seg_l.row0:], nl, D)
         ops.scatter_token_rows(dX[nl:], P["dev"]["student_global_src"], d_xnf[seg_g.row0:], Ts - nl, D)
-        return out
 
     def _sinkhorn_targets(self, ws, t_logits, probs, P, B2, Tm, K):
         """Sinkhorn-Knopp teacher targets (DINOv2 sinkhorn_knopp_teacher) for the cls rows and for the masked-patch rows.  Under
@@ -573,6 +607,7 @@ class VTPTrainer:
         yield ends a hipGraph segment: nothing forked may be left open there); what is still queued after the last event runs on
         the main stream in the optimizer leg of the body."""
         self._reduced_ranges = []
+        self._head_keys = []
         self._opt_queue, self._opt_done, self._hooks_done = [], [], set()
         self._opt_ema = ssl is not None
         lag = 2 if self.collectives else 1
@@ -808,6 +843,16 @@ class VTPTrainer:
         # of the trunk backward, whose 20 ms hide their reductions / updates.  (Round 4 joined at the decoder's second event, i.e.
         # after bucket_blocks blocks: the rest of the text backward then ran alone on a mostly empty chip -- measured same-box with
         # bucket_blocks 3 -> 12: 686 -> 705 images/s, all of it from this join)
+        def join_head():
+            # the SSL head ran on its own stream (_ssl_gen): joined in front of the first event since its fork (an event ends a graph
+            # segment) -- with a text tower that is the held event behind the decoder backward -- and at the latest here, in front of
+            # the trunk backward its d_xnf rows feed
+            if not self._head_keys:
+                return []
+            main.wait_stream(self._head_stream)
+            keys, self._head_keys = self._head_keys, []
+            return keys
+
         dec_gen = self._tower_backward("dec", self.decoder.backward(dt), self.decoder.depth)
         d_lat = None
         while True:
@@ -819,7 +864,12 @@ class VTPTrainer:
             if held is not None:
                 held += ev
                 continue
-            yield ev
+            yield join_head() + ev
+        keys = join_head()
+        if held is not None:
+            held += keys
+        elif keys:
+            yield keys
         if held is not None:
             main.wait_stream(T)
             yield held
