@@ -441,10 +441,7 @@ class VTPTrainer:
         into the trunk's d_xnf rows.  The trunk backward itself is run once by the caller, over all items.  Returns the
         ssl_forward() dict."""
         from .vtp import ssl_forward
-        model, st, head = self.model, self.store, self.ssl_head
-        dist = self.bucketer.dist
-        K, D = head.K, self.trunk.D
-        out = ssl_forward(model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
+        out = ssl_forward(self.model, P["global"], P["local"], P["masks"], P["plan"], P["dev"], train=True, lead_images=lead_images)
         self._zero_join()  # the gradient buffer was zeroed under the forward passes; the head backward below is its first writer
         if not (self.head_overlap and not self.collectives and OVERLAP.enabled):
             yield from self._ssl_tail(out, P)
