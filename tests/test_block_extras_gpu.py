@@ -276,34 +276,50 @@ def test_rope_train_time_augmentations_vs_oracle():
     assert relF(lat, lat_ref) < 1.5e-2
     m.train()
     tr = VTPTrainer(m, lr=0.0, weight_decay=0.0)
+    KEYS = ["trunk.blocks.0.attn.qkv.weight", "trunk.blocks.2.attn.qkv.bias", "trunk.blocks.1.attn.proj.weight",
+            "trunk.blocks.0.mlp.w3.weight", "trunk.patch_embed.proj.weight", "pixel_decoder.blocks.0.attn.qkv.weight",
+            "pixel_decoder.blocks.1.attn.qkv.bias", "pixel_decoder.blocks.1.mlp.w1.weight", "pixel_decoder.proj_in.weight"]
+
+    def check(trn, mod, loss, what):
+        """loss / gradients of the step that just ran against the oracle evaluated with THAT step's draws"""
+        torch.cuda.synchronize()
+        d_tr, d_dec = trn.trunk.rope_aug.last_draws, trn.decoder.rope_aug.last_draws
+        assert len(d_tr) == trn.trunk.depth and len(d_tr[0]) == 1 and len(d_dec) == 1
+        assert not torch.equal(d_tr[0][0]["shift"], d_tr[1][0]["shift"]), "every block draws its own coordinates"
+        aug_tr, aug_dec = [row[0] for row in d_tr], d_dec[0][0]
+
+        def ref_loss(s_):
+            out = O.trunk_forward(s_, img, 2, use_bottleneck=True, rope_aug=aug_tr)
+            return O.l1_loss(O.decoder_forward(s_, out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, rope_aug=aug_dec), img)
+
+        ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+        loss_ref = ref_loss(ref)
+        loss_ref.backward()
+        ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            l16 = ref_loss(ref16)
+        l16.backward()
+        print(f"RoPE augmentation [{what}]: loss ours {float(loss):.5f} oracle (same draws) {float(loss_ref):.5f}")
+        assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
+        _compare_grads(mod, ref, KEYS, 3e-2, ref16)
+        return d_tr, d_dec
+
     loss = tr.step_rec(img.to(DEV))
-    torch.cuda.synchronize()
-    d_tr, d_dec = tr.trunk.rope_aug.last_draws, tr.decoder.rope_aug.last_draws
-    assert len(d_tr) == tr.trunk.depth and len(d_tr[0]) == 1 and len(d_dec) == 1
-    assert not torch.equal(d_tr[0][0]["shift"], d_tr[1][0]["shift"]), "every block draws its own coordinates"
-    aug_tr, aug_dec = [row[0] for row in d_tr], d_dec[0][0]
-
-    def ref_loss(s_):
-        out = O.trunk_forward(s_, img, 2, use_bottleneck=True, rope_aug=aug_tr)
-        return O.l1_loss(O.decoder_forward(s_, out["x_norm_patchtokens"].transpose(1, 2).reshape(B, -1, 4, 4), 2, rope_aug=aug_dec), img)
-
-    ref = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
-    loss_ref = ref_loss(ref)
-    loss_ref.backward()
-    ref16 = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items()}
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        l16 = ref_loss(ref16)
-    l16.backward()
+    d_tr, d_dec = check(tr, m, loss, "eager, step 1")
     with torch.no_grad():
         plain = O.rec_train_loss(sd, img, 2, 2)
-    print(f"RoPE augmentation: loss ours {float(loss):.5f} oracle (same draws) {float(loss_ref):.5f} oracle without augmentation {float(plain):.5f}")
-    assert abs(float(loss) - float(loss_ref)) < 3e-3 * float(loss_ref)
-    _compare_grads(m, ref, ["trunk.blocks.0.attn.qkv.weight", "trunk.blocks.2.attn.qkv.bias", "trunk.blocks.1.attn.proj.weight",
-                            "trunk.blocks.0.mlp.w3.weight", "trunk.patch_embed.proj.weight", "pixel_decoder.blocks.0.attn.qkv.weight",
-                            "pixel_decoder.blocks.1.mlp.w1.weight", "pixel_decoder.proj_in.weight"], 3e-2, ref16)
-    # fresh draws every step; the hipGraph path re-draws into the static buffers before each replay
-    tr.step_rec(img.to(DEV))
-    assert not torch.equal(tr.trunk.rope_aug.last_draws[0][0]["shift"], d_tr[0][0]["shift"])
+    print(f"   oracle without augmentation {float(plain):.5f}")
+    # fresh draws every step -- and the forward rotates with THEM (ADVICE r5: the decoder's fused qkv + RoPE epilogue used to keep a
+    # cached copy of the first step's table while the backward un-rotated with the fresh one): step 2 against the oracle with step 2's draws
+    loss2 = tr.step_rec(img.to(DEV))
+    d_tr2, d_dec2 = check(tr, m, loss2, "eager, step 2")
+    assert not torch.equal(d_tr2[0][0]["shift"], d_tr[0][0]["shift"]) and not torch.equal(d_dec2[0][0]["shift"], d_dec[0][0]["shift"])
+    # the hipGraph path re-draws into the static buffers before each replay: lr = 0, so every replayed step is comparable to the oracle
+    m3, _ = _model(None, **kw)
+    t3 = VTPTrainer(m3, lr=0.0, weight_decay=0.0, use_graphs=True)
+    for _ in range(3):
+        loss3 = t3.step_rec(img.to(DEV))
+    check(t3, m3, loss3, "graphs, step 3")
     m2, _ = _model(None, **kw)
     t2 = VTPTrainer(m2, lr=1e-3, weight_decay=0.0, use_graphs=True)
     ls = [float(t2.step_rec(img.to(DEV))) for _ in range(4)]

@@ -69,8 +69,11 @@ def test_rope_tables_match_oracle():
 
 
 def test_range_helpers():
-    from vtp_amd.train import merge_ranges, param_ranges
+    from vtp_amd.train import merge_ranges, param_ranges, uncovered
     assert merge_ranges([(8, 12), (0, 4), (4, 8), (20, 24)]) == [(0, 12), (20, 24)]
+    # EMA pairs the optimizer lane did not touch on a step (train.py, optimizer leg): the parts of a student range outside the updated ranges
+    assert uncovered(10, 30, [(0, 12), (20, 24)]) == [(12, 20), (24, 30)]
+    assert uncovered(10, 30, [(0, 40)]) == [] and uncovered(10, 30, []) == [(10, 30)] and uncovered(10, 30, [(30, 50), (0, 10)]) == [(10, 30)]
     offs = {"trunk.a": (0, 6), "visual_proj.weight": (8, 4), "pixel_decoder.b": (12, 8), "text.c": (20, 3)}
     assert param_ranges(offs, ("trunk.", "pixel_decoder.")) == [(0, 8), (12, 20)]
 

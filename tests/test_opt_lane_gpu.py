@@ -123,3 +123,42 @@ def test_lane_rec_only_and_rec_clip_steps(sslg):
     for _ in range(3):
         c1 = float(tr.step(img, txt)[1])
     assert c1 < c0
+
+
+def test_lane_emas_every_pair_on_a_step_without_text(sslg):
+    """rec + DINO/iBOT WITHOUT captions on a model that has a CLIP head: visual_proj gets no gradient (it is outside the step's ranges),
+    but update_teacher (vtp.py:392-401) still moves teacher_proj towards it -- the lane's optimizer leg EMAs the pairs its buckets did not
+    touch, like the serial leg"""
+    from oracle.make_golden_ssl import SSL_CFG as C
+    from vtp_amd import VTPTrainer
+    from vtp_amd.vtp import _range
+    g, sd = sslg
+    img = torch.randn(C["B"], 3, C["R"], C["R"], device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    res = {}
+    for tag, lane in (("serial", False), ("lane", True)):
+        torch.manual_seed(0)
+        m = build_vtp(sd)
+        st = m._engine()
+        proj = [(t, s) for t, s in m.ema_pairs() if t == "teacher_proj."]
+        if not proj:
+            pytest.skip("model without a teacher_proj pair")
+        (tlo, thi), (slo, shi) = _range(st, proj[0][0]), _range(st, proj[0][1])
+        with torch.no_grad():  # teacher_proj != visual_proj, so that an EMA step is visible
+            st.flat_p[tlo:thi].add_(0.5)
+        before = st.flat_p[tlo:thi].clone()
+        tr = VTPTrainer(m, lr=5e-4, weight_decay=0.05, teacher_momentum=0.9)
+        tr.overlap_opt = lane
+        ssl = tr.prepare_ssl(g["in.global_crops"].to(DEV), g["in.local_crops"].to(DEV), g["in.masks"].bool())
+        for _ in range(2):
+            tr.step(img, None, ssl)
+        torch.cuda.synchronize()
+        assert not torch.equal(st.flat_p[tlo:thi], before), f"{tag}: teacher_proj did not move"
+        exp = 0.9 * 0.9 * before + (1 - 0.81) * st.flat_p[slo:shi]  # the student's proj is constant on these steps
+        assert torch.allclose(st.flat_p[tlo:thi], exp, rtol=1e-5, atol=1e-6), tag
+        res[tag] = (st.flat_p.clone(), st.flat_bf16.clone())
+        ref = st.flat_bf16.clone()
+        st.prep()
+        torch.cuda.synchronize()
+        assert torch.equal(st.flat_bf16, ref), f"{tag}: a weight copy is stale"
+    for a, b, name in zip(res["lane"], res["serial"], ("params", "bf16 copies")):
+        assert relF(a, b) <= 2e-5, name

@@ -119,26 +119,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       constexpr int TPB = 32 * CPR / 64;  // 16-B items per lane and 32-row block
       // the lane's bias values do not depend on the row block: ONE round of loads per tile (in front of the first block's
       // conversions) instead of one L2 round trip inside every block
-      // XMODE 1 (apply_rope) keeps the rotation tables of a row block in registers across the block loop (below) and has no room for
-      // the bias values beside them: there the bias goes into the accumulators in a pre-pass (same two roundings per element)
+      // (XMODE 1, apply_rope, keeps the bias values like the plain variant: a pre-pass that moved the bias into the accumulators to free
+      // registers for the rotation tables was tried in round 5 and measured no faster; removed)
       constexpr bool HAS_BIAS = XMODE != 2;  // (the SwiGLU-backward instantiation is a dgrad: no bias, no registers for one)
       f32x4 bias_v[HAS_BIAS ? TN : 1][4];
-      if constexpr (XMODE == 77) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = n0 + wn * WTN + i * 32 + 8 * q + 4 * hi;
-            const f32x4 b = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float v = acc[i][j][4 * q + e] * p.alpha;
-                acc[i][j][4 * q + e] = v + b[e];
-              }
-          }
-      }
       if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)

@@ -499,7 +499,10 @@ class Stack:
     @staticmethod
     def _plan_tabs(plan, i: int):
         """sin / cos operands of the fused epilogue for block i"""
-        return (plan[1][i], plan[2][i]) if plan[1].ndim == 3 else (plan[1], plan[2])
+        if plan[1].ndim == 3:  # static per-block buffers of RopeAugTabs (refreshed in place); [1, P, 64]: one draw for every block
+            i = min(i, plan[1].shape[0] - 1)
+            return plan[1][i], plan[2][i]
+        return plan[1], plan[2]
 
     # ------------------------------------------------------------------------------------------------ stochastic depth
     # block.py:20-118 (get_branges_scales) and :207-289: in training with drop_ratio > 0 every residual branch of every block runs
@@ -1017,6 +1020,7 @@ class RopeAugTabs:
         self.sin_all, self.cos_all, self.off, self.hw = sin_all, cos_all, off, hw
 
     def at(self, i: int):
+        i = min(i, self.sin_all.shape[0] - 1)  # one shared draw for all blocks (pixel decoder): buffers [1, P, 64]
         return self.sin_all[i, self.off:self.off + self.hw], self.cos_all[i, self.off:self.off + self.hw]
 
 
@@ -1040,9 +1044,22 @@ class RopeAugmenter:
     def __init__(self, periods: torch.Tensor, depth: int, per_block: bool, shift, jitter, rescale, seed: int = 0):
         self.per, self.depth, self.per_block = periods.detach().to("cpu"), depth, per_block
         self.cfg = (shift, jitter, rescale)
+        self.engine_id = int(seed)
         self.gen = torch.Generator().manual_seed(int(seed))
         self.records: Dict[tuple, dict] = {}
+        self.touched = set()    # record keys handed out since the trainer last cleared it (what ONE captured step reads)
         self.last_draws = None  # [[draw dict per item] per block] of the latest refresh (tests replay them into the oracle)
+
+    def reseed(self, base_seed: int, rank: int = 0):
+        """the reference draws from the per-rank device RNG: data-parallel ranks must not share their augmentations.  The trainer
+        calls this with its seed and rank; the stream of a (seed, rank, engine) triple is reproducible."""
+        self.gen.manual_seed((int(base_seed) * 1000003 + int(rank)) * 8 + self.engine_id)
+
+    def get_state(self) -> torch.Tensor:
+        return self.gen.get_state().clone()
+
+    def set_state(self, state: torch.Tensor):
+        self.gen.set_state(state.to("cpu", torch.uint8))
 
     @property
     def active(self) -> bool:
@@ -1101,6 +1118,7 @@ class RopeAugmenter:
     def tables(self, key, hws, device):
         """the record of this forward, refreshed unless the stream is being captured (then the trainer refreshes before each replay)"""
         rec = self.record(key, hws, device)
+        self.touched.add(key)
         if torch.cuda.is_current_stream_capturing():
             if not rec["fresh"]:
                 raise RuntimeError("RoPE augmentation tables must exist before stream capture (run the step eagerly once)")
@@ -1108,9 +1126,12 @@ class RopeAugmenter:
             self.refresh(rec)
         return rec
 
-    def refresh_all(self):
-        for rec in self.records.values():
-            self.refresh(rec)
+    def refresh_all(self, keys=None):
+        """new draws for the records a replayed graph reads (`keys`: what tables() handed out while that graph was captured; None:
+        every record ever created -- host cost and one event wait per record, so the trainer passes the keys)"""
+        for k, rec in self.records.items():
+            if keys is None or k in keys:
+                self.refresh(rec)
 
 
 # =====================================================================================================================
@@ -1317,7 +1338,9 @@ class DecoderEngine:
         rope = rope_tables(self.periods, h, w, st.device)
         if train and self.rope_aug.active:
             rec = self.rope_aug.tables((B, h, w), [(h, w)], st.device)
-            rope = (rec["sin"][0], rec["cos"][0])
+            # (RopeAugTabs, not a plain pair: _rope_plan keeps a COPY of plain tables, keyed by their address -- a buffer that is
+            # refreshed in place would leave the fused qkv + RoPE epilogue rotating with the first step's draw)
+            rope = RopeAugTabs(rec["sin"], rec["cos"], 0, h * w)
         dropped = train and self.stack.drop_plan is not None
         if dropped:
             xl = self.stack.forward_drop(ws, x0, [(B, h * w, rope)], 0)

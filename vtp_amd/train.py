@@ -204,6 +204,20 @@ def merge_ranges(ranges: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
     return out
 
 
+def uncovered(lo: int, hi: int, covered: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """the parts of [lo, hi) that none of the (merged, sorted) `covered` ranges contains"""
+    out, x = [], lo
+    for a, b in covered:
+        if b <= x or a >= hi:
+            continue
+        if a > x:
+            out.append((x, a))
+        x = max(x, b)
+    if x < hi:
+        out.append((x, hi))
+    return out
+
+
 def param_ranges(offsets, prefixes: Sequence[str]) -> List[Tuple[int, int]]:
     """Contiguous [lo,hi) ranges (4-element aligned) of the flat buffers covering every parameter whose name starts
     with one of `prefixes`."""
@@ -347,6 +361,9 @@ class VTPTrainer:
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
         self._comm_events = []
         self.world, self.rank, self.group = self.bucketer.world, self.bucketer.rank, group
+        for eng in self._aug_engines():  # train-time RoPE augmentations: one stream per (seed, rank, engine), as the reference's per-rank RNG
+            eng.rope_aug.reseed(drop_seed, self.rank)
+        self._graph_aug = {}  # graph key -> [(engine, record keys its captured segments read)]
         self.bucket_blocks = bucket_blocks
         self._bucket_plan = self._plan_buckets()
         # hyper-parameters live in device memory so that captured hipGraphs replay with per-step values
@@ -909,6 +926,18 @@ class VTPTrainer:
         if text is not None:
             st.p("logit_scale").clamp_(max=math.log(100.0))  # OpenCLIP training-loop convention
         if self.overlap_opt:  # EMA and the weight refresh rode along bucket by bucket
+            if ssl is not None:
+                # ... for the student ranges this step UPDATED.  update_teacher (vtp.py:392-401) moves every EMA pair on every call:
+                # a pair whose student got no gradient on this step (visual_proj on an SSL step without captions) still decays
+                # towards it -- the serial leg below does that too
+                from .vtp import _range
+                done = merge_ranges(self._opt_done)
+                for t_pref, s_pref in self.model.ema_pairs():
+                    (tlo, thi), (slo, shi) = _range(st, t_pref), _range(st, s_pref)
+                    for a, b in uncovered(slo, shi, done):
+                        ta = tlo + (a - slo)
+                        ops.ema_dev(st.flat_p[ta:ta + b - a], st.flat_p[a:b], b - a, self.momentum_dev)
+                        st.prep_runs(st.desc_runs([(ta, ta + b - a)]))
             st.mark_prepped(self._hooks_done)
             return
         if ssl is not None:  # EMA teacher (vtp.py:388-401) on the freshly updated student
@@ -1098,6 +1127,10 @@ class VTPTrainer:
 
     # ---- training-state checkpoint: the model's own state_dict (student, teacher, heads) travels in the
     # reference's HF layout; this is the rest of the state a resumed run needs
+    def _aug_engines(self):
+        return [e for e in (getattr(self, "trunk", None), getattr(self, "decoder", None), getattr(self.model, "_t_trunk", None))
+                if e is not None and hasattr(e, "rope_aug")]
+
     def state_dict(self) -> dict:
         """Optimizer moments (as name -> tensor, the same keys as model.state_dict()), step counter and SSL centres.
         With shard_optimizer the moments are gathered from their owners: this is a COLLECTIVE call -- every rank must make it
@@ -1110,6 +1143,9 @@ class VTPTrainer:
             sd["exp_avg_sq"][name] = v[o:o + k].detach().clone().view(st.params[name].shape).cpu()
         if self.ssl_head is not None:
             sd["center_dino"], sd["center_ibot"] = self.center_dino.cpu().clone(), self.center_ibot.cpu().clone()
+        aug = [e.rope_aug.get_state() for e in self._aug_engines() if e.rope_aug.active]
+        if aug:  # this rank's RoPE-augmentation streams (per-rank state: saved and restored rank by rank)
+            sd["rope_aug_rng"] = aug
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -1124,6 +1160,10 @@ class VTPTrainer:
         if self.ssl_head is not None and "center_dino" in sd:
             self.center_dino.copy_(sd["center_dino"])
             self.center_ibot.copy_(sd["center_ibot"])
+        engs = [e for e in self._aug_engines() if e.rope_aug.active]
+        if "rope_aug_rng" in sd and len(sd["rope_aug_rng"]) == len(engs):
+            for e, stt in zip(engs, sd["rope_aug_rng"]):
+                e.rope_aug.set_state(stt)
         self.sync_replicas()
 
     # ---- hipGraph path: one captured graph per segment, replayed every step; collectives between segments ----------
@@ -1171,6 +1211,8 @@ class VTPTrainer:
             del snap
             segs = []
             pool = torch.cuda.graph_pool_handle()
+            for eng in self._aug_engines():
+                eng.rope_aug.touched.clear()
             gen = self._step_gen(static_img, static_txt, static_ssl, static_rec)
             done = False
             while not done:
@@ -1191,12 +1233,12 @@ class VTPTrainer:
                 segs.append((g, ev))
             plan = (static_img, static_txt, static_ssl, segs, static_rec)
             self._graphs[key] = plan
+            self._graph_aug[key] = [(eng, frozenset(eng.rope_aug.touched)) for eng in self._aug_engines() if eng.rope_aug.active]
         static_img, static_txt, static_ssl, segs, static_rec = plan
         # train-time RoPE augmentations: fresh draws into the static table buffers the captured segments read (an eager step
         # draws inside its forward passes; under capture nothing can be drawn)
-        for eng in (self.trunk, self.decoder, getattr(self.model, "_t_trunk", None)):
-            if eng is not None and eng.rope_aug.active:
-                eng.rope_aug.refresh_all()
+        for eng, keys in self._graph_aug.get(key, ()):
+            eng.rope_aug.refresh_all(keys)
         static_img.copy_(images)
         if rec_images is not None:
             static_rec.copy_(rec_images)
