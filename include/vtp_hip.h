@@ -72,6 +72,12 @@ int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int spl
 /* the same launch with the kernel named: 0 = the 8-phase kernel (= vtp_gemm_tn_grouped), 1 = the one-wave-per-SIMD kernel with the
  * hand-scheduled k loop (needs K % 8 == 0; bit-identical results per K slice) */
 int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket, int kernel, void* stream);
+/* the same launch (one-wave-per-SIMD kernel, K % 8 == 0) from an explicit work-item list, so that the tiles need not be cut alike: items =
+ * device array of nitems records of 8 int32 {tile, kbeg, kcount, nparts, part, 0, 0, 0}, one workgroup each; the items of a tile partition
+ * [0, K) (kbeg multiples of 64); slots = the largest nparts; part: ntiles * slots * 65536 floats.  The tiles that also form a bias gradient
+ * (column sums of dY beside the MFMAs: 27 % more time per k-tile) get one slice more than the rest -- same reference call sites as above. */
+int vtp_gemm_tn_grouped_items(const void* probs, int nprob, int ntiles, int K, const void* items, int nitems, int slots, void* part,
+                              void* ticket, void* stream);
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);

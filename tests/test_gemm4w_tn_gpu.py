@@ -50,7 +50,7 @@ def test_grouped_wgrad_one_wave_kernel(Ktok, D, H):
         torch.cuda.synchronize()
         if grp.splits > 1:
             assert int(scratch["ticket"].abs().sum()) == 0, "tickets must return to zero"
-        res[kernel] = (gws, gbs, grp.splits, grp.ntiles)
+        res[kernel] = (gws, gbs, max(grp.splits, grp.slots), grp.ntiles)
     print(f"grouped wgrad Ktok={Ktok}: {res[1][3]} tiles x {res[1][2]} slices")
     for n, ((a, x, N, K, sh, cs), w0, b0) in enumerate(zip(probs, gw0, gb0)):
         ref = a.float().T @ x.float()  # [N, K]

@@ -587,3 +587,38 @@ def test_shipped_kernels_spill_ratchet():
         assert hit, f"kernel {k} not in the built objects"
         for n in hit:
             assert rows[n][0] <= cap, f"{n}: {rows[n][0]} spilled VGPRs (cap {cap})"
+
+
+def test_wgrad_group_item_list_partitions_every_tile():
+    """ops.wgrad_group_items (the uneven cut of the grouped weight-gradient launch): every tile's items partition [0, K) at multiples of
+    64, slots are numbered 0 .. nparts - 1, the bias-gradient tiles (first tile column of a problem with a colsum target) get one slice
+    more than the rest while the launch still fits one round of the CUs, and never otherwise"""
+    from vtp_amd.ops import wgrad_group_items, wgrad_group_splits
+
+    def rows(D, H):  # the four problems of a ViT block as WgradGroup.add records them: w3, w12 (+bias), proj, qkv (+bias)
+        out, t0 = [], 0
+        for N, K, gb in ((D, H, 0), (2 * H, D, 1), (D, D, 0), (3 * D, D, 1)):
+            out.append([1, 2, 3, gb, N, K, K, N, K, 0, 0, t0, 1, 0, 0, 0])
+            t0 += ((N + 255) // 256) * ((K + 255) // 256)
+        return out, t0
+
+    for D, H, Ktok in ((768, 2048, 34144), (768, 2048, 8192), (1024, 2736, 34144), (384, 1024, 65792), (768, 2048, 2048)):
+        rs, ntiles = rows(D, H)
+        _, base = wgrad_group_splits(ntiles, Ktok)
+        items, slots = wgrad_group_items(rs, Ktok, base)
+        by_tile = {}
+        for tile, kb, kc, n, z, *_ in items:
+            assert kb % 64 == 0 and kc > 0 and 0 <= z < n <= slots
+            by_tile.setdefault(tile, []).append((z, kb, kc, n))
+        assert sorted(by_tile) == list(range(ntiles))
+        heavy = 0
+        for tile, its in by_tile.items():
+            its.sort()
+            assert [z for z, *_ in its] == list(range(its[0][3])) and its[0][1] == 0
+            assert all(a[1] + a[2] == b[1] for a, b in zip(its, its[1:])) and its[-1][1] + its[-1][2] == Ktok
+            heavy += its[0][3] > base
+        ncs = sum(((r[7] + 255) // 256) for r in rs if r[3])
+        fits = ntiles * base + ncs <= 256 and Ktok // (base + 1) >= 1024
+        assert heavy == (ncs if fits else 0) and len(items) <= max(256, ntiles * base), (D, Ktok, heavy, ncs, len(items))
+        if (D, Ktok) == (768, 34144):
+            assert (base, slots, len(items)) == (2, 3, 241)

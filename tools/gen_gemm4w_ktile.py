@@ -216,6 +216,10 @@ def main():
     # ---- TN
     txt = "// GENERATED by tools/gen_gemm4w_ktile.py -- do not edit.  See that script for the schedule.\n"
     txt += emit("W4T_TILE_ASM", tn_body(False)) + "\n" + emit("W4T_TILE_ASM_CSUM", tn_body(True))
+    # both loops behind ONE scalar branch in ONE asm statement (%[docs] != 0: with column sums).  As two statements in the two arms of a
+    # C++ branch, hipcc merged the 256 accumulator registers of the arms through scratch (64 spilled VGPRs, round-5 review)
+    both = ["s_cmp_eq_u32 %[docs], 0", "s_cbranch_scc1 8f"] + tn_body(True) + ["s_branch 9f", "8:"] + tn_body(False) + ["9:"]
+    txt += "\n" + emit("W4T_TILE_ASM_BOTH", both)
     txt += f"\n#define W4T_TILE_ACC {acc}\n"
     txt += "#define W4T_TILE_CLOBBERS " + ", ".join(f'"v{r}"' for r in range(64, 256)) + "\n"
     open(OUT.replace("gemm4w_ktile", "gemm4w_tn_ktile"), "w").write(txt)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "vtp_gemm_tn": [_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "vtp_gemm_tn_grouped": [_P, _I, _I, _I, _I, _P, _P, _P],
     "vtp_gemm_tn_grouped_k": [_P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "vtp_gemm_tn_grouped_items": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "vtp_colsum_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vtp_colsum_bf16_rows": [_P, _I, _P, _P, _I, _I, _P],
     "vtp_gather_image_rows": [_P, _P, _P, _P, _I, _L, _I, _F, _P],

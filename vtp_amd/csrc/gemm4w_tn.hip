@@ -48,30 +48,23 @@ struct W4TStage {  // wave-uniform staging constants
   unsigned stepa, stepb, da[2], db[2];
 };
 
-template <bool CSUM>
-__device__ __forceinline__ void w4t_kloop(f32x16 (&acc)[4][4], float (&cs)[4], const unsigned (&aE)[2], const unsigned (&aO)[2],
+// the k loop of a (tile, K range): ONE asm statement holding both generated loops (with / without the bias-gradient column sums) behind
+// a scalar branch -- see tools/gen_gemm4w_ktile.py
+__device__ __forceinline__ void w4t_kloop(bool csum, f32x16 (&acc)[4][4], float (&cs)[4], const unsigned (&aE)[2], const unsigned (&aO)[2],
                                           const unsigned (&bE)[2], const unsigned (&bO)[2], unsigned& pea, unsigned& peb, unsigned zoff,
                                           const W4TStage& st, int& kra, int& krb, unsigned nk2) {
   unsigned vt, sm, cnt = nk2;
   unsigned long long sb;
   const unsigned ones = 0x3F803F80u;
-  if constexpr (CSUM) {
-    asm volatile(W4T_TILE_ASM_CSUM
-                 : W4T_TILE_ACC, [cs0] "+v"(cs[0]), [cs1] "+v"(cs[1]), [cs2] "+v"(cs[2]), [cs3] "+v"(cs[3]), [pea] "+v"(pea), [peb] "+v"(peb),
-                   [vt] "=&v"(vt), [kra] "+s"(kra), [krb] "+s"(krb), [cnt] "+s"(cnt), [sm] "=&s"(sm), [sb] "=&s"(sb)
-                 : [aE0] "v"(aE[0]), [aO0] "v"(aO[0]), [bE0] "v"(bE[0]), [bO0] "v"(bO[0]), [aE1] "v"(aE[1]), [aO1] "v"(aO[1]), [bE1] "v"(bE[1]),
-                   [bO1] "v"(bO[1]), [zoff] "v"(zoff), [mata] "s"(st.mata), [matb] "s"(st.matb), [zb] "s"(st.zb), [stepa] "s"(st.stepa),
-                   [stepb] "s"(st.stepb), [ones] "s"(ones), [da0] "s"(st.da[0]), [da1] "s"(st.da[1]), [db0] "s"(st.db[0]), [db1] "s"(st.db[1])
-                 : "memory", "scc", "vcc", W4T_TILE_CLOBBERS);
-  } else {
-    asm volatile(W4T_TILE_ASM
-                 : W4T_TILE_ACC, [pea] "+v"(pea), [peb] "+v"(peb), [vt] "=&v"(vt), [kra] "+s"(kra), [krb] "+s"(krb), [cnt] "+s"(cnt),
-                   [sm] "=&s"(sm), [sb] "=&s"(sb)
-                 : [aE0] "v"(aE[0]), [aO0] "v"(aO[0]), [bE0] "v"(bE[0]), [bO0] "v"(bO[0]), [aE1] "v"(aE[1]), [aO1] "v"(aO[1]), [bE1] "v"(bE[1]),
-                   [bO1] "v"(bO[1]), [zoff] "v"(zoff), [mata] "s"(st.mata), [matb] "s"(st.matb), [zb] "s"(st.zb), [stepa] "s"(st.stepa),
-                   [stepb] "s"(st.stepb), [da0] "s"(st.da[0]), [da1] "s"(st.da[1]), [db0] "s"(st.db[0]), [db1] "s"(st.db[1])
-                 : "memory", "scc", "vcc", W4T_TILE_CLOBBERS);
-  }
+  const unsigned docs = __builtin_amdgcn_readfirstlane(csum ? 1u : 0u);
+  asm volatile(W4T_TILE_ASM_BOTH
+               : W4T_TILE_ACC, [cs0] "+v"(cs[0]), [cs1] "+v"(cs[1]), [cs2] "+v"(cs[2]), [cs3] "+v"(cs[3]), [pea] "+v"(pea), [peb] "+v"(peb),
+                 [vt] "=&v"(vt), [kra] "+s"(kra), [krb] "+s"(krb), [cnt] "+s"(cnt), [sm] "=&s"(sm), [sb] "=&s"(sb)
+               : [aE0] "v"(aE[0]), [aO0] "v"(aO[0]), [bE0] "v"(bE[0]), [bO0] "v"(bO[0]), [aE1] "v"(aE[1]), [aO1] "v"(aO[1]), [bE1] "v"(bE[1]),
+                 [bO1] "v"(bO[1]), [zoff] "v"(zoff), [mata] "s"(st.mata), [matb] "s"(st.matb), [zb] "s"(st.zb), [stepa] "s"(st.stepa),
+                 [stepb] "s"(st.stepb), [ones] "s"(ones), [docs] "s"(docs), [da0] "s"(st.da[0]), [da1] "s"(st.da[1]), [db0] "s"(st.db[0]),
+                 [db1] "s"(st.db[1])
+               : "memory", "scc", "vcc", W4T_TILE_CLOBBERS);
 }
 
 // one (tile, K range) of a grouped launch: k rows [kbeg, kbeg + kcount) of the tile's reduction; `nparts` workgroups share the tile and
@@ -80,6 +73,19 @@ __device__ __forceinline__ void w4t_kloop(f32x16 (&acc)[4][4], float (&cs)[4], c
 __device__ __forceinline__ void w4t_segment(const GroupArgs& ga, int tile, int kbeg, int kcount, int nparts, int part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
+  // diagnostics (vtp_gemm_debug, tools/wgrad_timeline.py): 100-MHz stamps per workgroup -- [0] start, [1] first operands landed,
+  // [2] k loop done, [3] published + ticket drawn, [4] done, [5] tile, [6] K slice, [7] XCC id
+  auto stamp = [&](int which) {
+    if (__builtin_expect(ga.timing != nullptr, 0) && tid == 0) ga.timing[(size_t)blockIdx.x * 8 + which] = wall_clock64();
+  };
+  if (__builtin_expect(ga.timing != nullptr, 0) && tid == 0) {
+    ga.timing[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)tile;
+    ga.timing[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)part;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ga.timing[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 15);
+  }
+  stamp(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -161,9 +167,10 @@ __device__ __forceinline__ void w4t_segment(const GroupArgs& ga, int tile, int k
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (do_csum) w4t_kloop<true>(acc, cs, aE, aO, bE, bO, pea, peb, zoff, st, kra, krb, nk2);
-  else w4t_kloop<false>(acc, cs, aE, aO, bE, bO, pea, peb, zoff, st, kra, krb, nk2);
+  stamp(1);
+  w4t_kloop(do_csum, acc, cs, aE, aO, bE, bO, pea, peb, zoff, st, kra, krb, nk2);
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7\n\ts_waitcnt vmcnt(0)" ::: "memory");  // last MFMA passes; surplus zero pieces
+  stamp(2);
 
   if (do_csum && wc == 0) {
 #pragma unroll
@@ -199,18 +206,22 @@ __device__ __forceinline__ void w4t_segment(const GroupArgs& ga, int tile, int k
       *flag = last;
     }
     __syncthreads();
+    stamp(3);
     if (*flag == 0) return;
     for (int z = 0; z < nparts; ++z) {
       if (z == part) continue;
       const f32x4* other = (const f32x4*)ga.part + (((size_t)tile * ga.splits + z) * 4 + wave) * 4096 + lane;
+      // NLD 16-B loads in flight per lane (the fragment registers v64..v255 are dead here): a partial tile is 64 loads per lane, and
+      // with 8 in flight its 8 dependent round trips were most of the last arriver's combine (tools/wgrad_timeline.py)
+      constexpr int NLD = 16;
 #pragma unroll
-      for (int gq = 0; gq < 8; ++gq) {
-        f32x4 v[8];
+      for (int gq = 0; gq < 64 / NLD; ++gq) {
+        f32x4 v[NLD];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = other[(gq * 8 + t) * 64];
+        for (int t = 0; t < NLD; ++t) v[t] = other[(gq * NLD + t) * 64];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int u = gq * 8 + t;
+        for (int t = 0; t < NLD; ++t) {
+          const int u = gq * NLD + t;
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[u >> 4][(u >> 2) & 3][4 * (u & 3) + e] += v[t][e];
         }
@@ -223,6 +234,7 @@ __device__ __forceinline__ void w4t_segment(const GroupArgs& ga, int tile, int k
   char* reg = smem + W4T_RING + wave * 8192;
   gemm_epilogue<EPI_F32, false, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[0], reg, m0, n0, wr, wc * 2, lane, 0, nullptr);
   gemm_epilogue<EPI_F32, false, 128, 64, 4096, 0>(p, *(f32x16(*)[2][4]) & acc[2], reg, m0, n0, wr, wc * 2 + 1, lane, 0, nullptr);
+  stamp(4);
 }
 
 
@@ -233,6 +245,26 @@ __global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_kernel(const GroupAr
   const int zslice = c / ga.ntiles, tile = c - zslice * ga.ntiles;
   const int kbeg = zslice * ga.k_split;
   w4t_segment(ga, tile, kbeg, min(ga.K, kbeg + ga.k_split) - kbeg, ga.splits, zslice);
+}
+
+// item-list launch (vtp_gemm_tn_grouped_items): every workgroup reads its (tile, K range, slot) from a host-built table, so the tiles of
+// a launch need not be cut alike -- the tiles that also sum the columns of A (bias gradients: 64 v_dot2 per k-tile beside the 64 MFMAs,
+// measured 27 % slower per k-tile, tools/wgrad_timeline.py) get one slice more than the others and the launch ends level
+__global__ __launch_bounds__(256, 1) void gemm4w_grouped_tn_items_kernel(const GroupArgs ga) {
+  const int W = gridDim.x, q = W >> 3, r = W & 7, x = blockIdx.x & 7;
+  const int c = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ((int)blockIdx.x >> 3);
+  const GroupItem& it = ga.items[c];
+  w4t_segment(ga, w4t_uni(it.tile), w4t_uni(it.kbeg), w4t_uni(it.kcount), w4t_uni(it.nparts), w4t_uni(it.part));
+}
+
+int launch_gemm4w_grouped_tn_items(const GroupArgs& ga, int nitems, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm4w_grouped_tn_items_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4T_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm4w_grouped_tn_items_kernel, dim3(nitems), dim3(256), W4T_LDS, s, ga);
+  return check_launch("gemm4w_grouped_tn_items");
 }
 
 // launcher used by vtp_gemm_tn_grouped_k (gemm8p.hip, kernel = 1).  The problem records live in DEVICE memory, so the C entry can only

@@ -720,6 +720,7 @@ int launch_gemm8p_tn(const GemmArgs& a, int epi, int splits, hipStream_t s) {
 // ntiles * splits * 256 KiB and ntiles ints (ticket zero-initialised by the caller once; the kernel leaves it zero).
 namespace vtp {
 int launch_gemm4w_grouped_tn(const GroupArgs& ga, hipStream_t s);  // gemm4w_tn.hip
+int launch_gemm4w_grouped_tn_items(const GroupArgs& ga, int nitems, hipStream_t s);
 }
 // kernel: 0 = the 8-phase kernel | 1 = the one-wave-per-SIMD kernel (gemm4w_tn.hip; the caller guarantees K % 8 == 0 and, as for
 // every grouped launch, M_g, N_g, lda, ldb multiples of 8 and operands within 32-bit byte offsets)
@@ -736,7 +737,7 @@ extern "C" int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, i
   ga.k_split = ((K + splits - 1) / splits + 63) / 64 * 64;
   ga.splits = (K + ga.k_split - 1) / ga.k_split;
   ga.timing = g_p8_timing;
-  if (kernel == 1 && !ga.timing) return launch_gemm4w_grouped_tn(ga, (hipStream_t)stream);
+  if (kernel == 1) return launch_gemm4w_grouped_tn(ga, (hipStream_t)stream);  // (stamps [workgroup][8] under vtp_gemm_debug)
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm8p_grouped_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
@@ -744,6 +745,23 @@ extern "C" int vtp_gemm_tn_grouped_k(const void* probs, int nprob, int ntiles, i
   }
   hipLaunchKernelGGL(gemm8p_grouped_tn_kernel, dim3(ntiles * ga.splits), dim3(512), P8_LDS, (hipStream_t)stream, ga);
   return check_launch("gemm8p_grouped_tn");
+}
+// The same launch from an explicit work-item list (one-wave-per-SIMD kernel only): items = device array of nitems records of 8 int32
+// {tile, kbeg, kcount, nparts, part, 0, 0, 0} -- one workgroup each; the items of a tile partition [0, K) into nparts ranges (kbeg
+// multiples of 64), part = 0 .. nparts - 1.  slots = the largest nparts: part holds ntiles * slots * 65536 floats.
+extern "C" int vtp_gemm_tn_grouped_items(const void* probs, int nprob, int ntiles, int K, const void* items, int nitems, int slots,
+                                         void* part, void* ticket, void* stream) {
+  using namespace vtp;
+  VTP_REQUIRE(probs && nprob >= 1 && nprob <= 8, "vtp_gemm_tn_grouped_items: 1..8 problems");
+  VTP_REQUIRE(items && nitems >= ntiles && ntiles >= 1 && K >= 8 && K % 8 == 0 && slots >= 1,
+              "vtp_gemm_tn_grouped_items: bad shape (ntiles %d, nitems %d, K %d, slots %d)", ntiles, nitems, K, slots);
+  VTP_REQUIRE(slots == 1 || (part && ticket), "vtp_gemm_tn_grouped_items: split tiles need the partial-sum and ticket buffers");
+  GroupArgs ga{};
+  ga.probs = (const GroupProblem*)probs; ga.part = (float*)part; ga.ticket = (int*)ticket;
+  ga.nprob = nprob; ga.ntiles = ntiles; ga.K = K; ga.k_split = K; ga.splits = slots;
+  ga.timing = g_p8_timing;
+  ga.items = (const GroupItem*)items;
+  return launch_gemm4w_grouped_tn_items(ga, nitems, (hipStream_t)stream);
 }
 extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket,
                                    void* stream) {

@@ -17,12 +17,19 @@ struct GroupProblem {  // 64-bit fields: written by the host as an int64 tensor
   long accumulate;  // 1: C += result, 0: C = result
   long pad[3];
 };
+struct GroupItem {  // one workgroup of an item-list launch (vtp_gemm_tn_grouped_items): 8 x int32, written by the host
+  int tile;           // index in the launch's tile list
+  int kbeg, kcount;   // its K range (kbeg a multiple of 64, kcount of 8)
+  int nparts, part;   // workgroups sharing the tile, and this one's slot among them
+  int pad[3];
+};
 struct GroupArgs {
   const GroupProblem* probs;
   float* part;
   int* ticket;
-  int nprob, ntiles, splits, K, k_split;
+  int nprob, ntiles, splits, K, k_split;  // splits: slices per tile (uniform launches) | partial-sum slots per tile (item lists)
   unsigned long long* timing;
+  const GroupItem* items;  // null: uniform tiles x splits geometry
 };
 
 }  // namespace vtp

@@ -299,6 +299,9 @@ FUSE_ROPE = True
 # (the per-layer path -- one split-K GEMM + slab reduce + column-sum launch per linear layer, beside that layer's dgrad -- is what
 # LayerScale, stochastic depth and tiny token counts use)
 WGRAD_GROUPED = True
+# experiment switch (round 6): VTP_WGRAD_INLINE=1 issues the grouped launch on the main stream (no side stream) -- what the overlap of the
+# dominant kernel with the next block's dgrad chain is worth in the step
+WGRAD_INLINE = _env_flag("VTP_WGRAD_INLINE", default="0")
 
 
 def linear_bwd(ws: Workspace, tag: str, L, dy_b, x_b, M: int, d_in, *, need_dx: bool = True, dy_remap=(0, 0),
@@ -457,6 +460,11 @@ class Stack:
             self.blocks.append(b)
         self.qk_norm = any(b.qn_w is not None for b in self.blocks)
         self.drop_plan = None  # stochastic depth (set per step by set_drop_plan)
+        # grouped weight-gradient launches write dW = ... instead of dW += ... while this is set: valid only where the caller has zeroed the
+        # gradients and runs this stack's backward ONCE before it reads them (VTPTrainer's step sets it; the autograd boundary, which
+        # must accumulate like nn.Parameter.grad does, never does).  Saves the 256-KiB read of every output tile in the epilogue of the
+        # step's dominant kernel: 38 -> 24 us per last-arriving workgroup (tools/wgrad_timeline.py)
+        self.wgrad_overwrite = False
 
     def _rope_plan(self, ws: Workspace, segs, prefix_tokens: int, M: int):
         """(rope_pos int32 [M], sin, cos) for the fused qkv + RoPE epilogue: rope_pos[m] = row of the concatenated per-segment
@@ -897,7 +905,7 @@ class Stack:
         def launch_pending():
             if pending is None:
                 return
-            if OVERLAP.enabled:
+            if OVERLAP.enabled and not WGRAD_INLINE:
                 OVERLAP.fork()
                 with torch.cuda.stream(OVERLAP.side):
                     pending[1].launch()
@@ -955,12 +963,13 @@ class Stack:
                 OVERLAP.join()
                 yield ("block", i)
                 continue
-            grp = groups.get(i)
+            gkey = (i, bool(self.wgrad_overwrite))
+            grp = groups.get(gkey)
             if grp is None:
                 grp = ops.WgradGroup(M)
                 for pr in probs:
-                    grp.add(pr["dy"], pr["x"], pr["gw"], pr["gb"], pr["N"], pr["K"], pr["swiglu_h"])
-                groups[i] = grp.finalize(self.store.device, scratch)
+                    grp.add(pr["dy"], pr["x"], pr["gw"], pr["gb"], pr["N"], pr["K"], pr["swiglu_h"], accumulate=not self.wgrad_overwrite)
+                groups[gkey] = grp.finalize(self.store.device, scratch)
             if pending is not None:
                 yield ("block", pending[0])  # its weight gradients are complete (joined above)
             pending = (i, grp)

@@ -193,6 +193,39 @@ def wgrad_group_kernel(ntiles: int, splits: int, Ktok: int) -> int:
     return 1 if Ktok // max(splits, 1) >= W4_TN_MIN_SLICE else 0
 
 
+def wgrad_group_items(rows, Ktok: int, base_splits: int, cus: int = 256):
+    """work-item list of a grouped launch on the one-wave-per-SIMD kernel (vtp_gemm_tn_grouped_items).  rows: the GroupProblem records
+    (WgradGroup.rows).  Every tile is cut into `base_splits` K ranges, except the tiles that also form a bias gradient -- the first tile
+    column of a problem with a colsum target: their k loop carries 64 v_dot2 per k-tile beside its 64 MFMAs and measures 27 % slower
+    (tools/wgrad_timeline.py: 470 vs 365 us at 34 144 rows) -- which get ONE MORE slice when the launch still fits one round of the CUs
+    and the shorter slice keeps >= 16 k-tiles.  Returns (items [n, 8] int32 rows {tile, kbeg, kcount, nparts, part, 0, 0, 0}, slots).
+    Order: per problem, the heavier-cut tiles first, slice-major inside a group -- the kernel deals contiguous chunks of the list to
+    the XCDs, so the workgroups that stream the same K range of the same operand panels sit behind one L2."""
+    def cuts(n):
+        ks = ((Ktok + n - 1) // n + 63) // 64 * 64
+        return [(b, min(Ktok, b + ks) - b) for b in range(0, Ktok, ks)]
+
+    tiles = []  # (tile index, problem, has colsum work)
+    for pi, r in enumerate(rows):
+        gb, N, K, tile0 = r[3], r[7], r[8], r[11]
+        tn = (K + 255) // 256  # the C of a problem is [N, K] (dW): "M" = N rows of dy's columns, "N" = K columns of x
+        for lt in range(((N + 255) // 256) * tn):
+            tiles.append((tile0 + lt, pi, gb != 0 and lt % tn == 0))
+    ncs = sum(1 for t in tiles if t[2])
+    more = ncs > 0 and len(tiles) * base_splits + ncs <= cus and Ktok // (base_splits + 1) >= 1024
+    items, slots = [], 1
+    for pi in range(len(rows)):
+        for heavy in (True, False):
+            grp = [t for t in tiles if t[1] == pi and t[2] == heavy]
+            if not grp:
+                continue
+            cs = cuts(base_splits + 1 if (heavy and more) else base_splits)
+            slots = max(slots, len(cs))
+            for z, (kb, kc) in enumerate(cs):
+                items += [[t[0], kb, kc, len(cs), z, 0, 0, 0] for t in grp]
+    return items, slots
+
+
 W4_TN_MIN_SLICE = 4096  # token rows per K slice from which the one-wave-per-SIMD kernel is taken (tools/wgrad_kernel_ab.py against the two-phase 8-phase kernel: x0.97 at 1232 .. 2048 rows, x1.01 at 4096, x1.06 at 8224, x1.08 .. 1.12 at 17072)
 
 
@@ -230,9 +263,16 @@ class WgradGroup:
         _, self.splits = wgrad_group_splits(self.ntiles, self.Ktok)
         self.table = torch.tensor(self.rows, dtype=torch.int64, device=device)
         self.kernel = wgrad_group_kernel(self.ntiles, self.splits, self.Ktok)
-        if self.splits > 1:
+        self.items, self.slots = None, self.splits
+        import os
+        if self.kernel == 1 and os.environ.get("VTP_WGRAD_ITEMS", "1") not in ("0", "false", "off"):
+            # uneven cut: the tiles with bias-gradient work get one slice more (wgrad_group_items); VTP_WGRAD_ITEMS=0: uniform geometry
+            items, self.slots = wgrad_group_items(self.rows, self.Ktok, self.splits)
+            self.nitems = len(items)
+            self.items = torch.tensor(items, dtype=torch.int32, device=device)
+        if self.slots > 1:
             scratch = {} if scratch is None else scratch
-            need = self.ntiles * self.splits * 65536
+            need = self.ntiles * self.slots * 65536
             if scratch.get("part") is None or scratch["part"].numel() < need:
                 scratch["part"] = torch.empty(need, dtype=torch.float32, device=device)
             if scratch.get("ticket") is None or scratch["ticket"].numel() < self.ntiles:
@@ -245,6 +285,10 @@ class WgradGroup:
         (ops.wgrad_group_kernel)"""
         if kernel is None:
             kernel = self.kernel
+        if kernel == 1 and self.items is not None:
+            _lib.check(_lib_().vtp_gemm_tn_grouped_items(_p(self.table), len(self.rows), self.ntiles, self.Ktok, _p(self.items), self.nitems,
+                                                         self.slots, _p(self.part), _p(self.ticket), _s()), "vtp_gemm_tn_grouped_items")
+            return
         _lib.check(_lib_().vtp_gemm_tn_grouped_k(_p(self.table), len(self.rows), self.ntiles, self.Ktok, self.splits, _p(self.part),
                                                   _p(self.ticket), kernel, _s()), "vtp_gemm_tn_grouped")
 

@@ -628,21 +628,31 @@ class VTPTrainer:
         # the lane is joined in front of every event when an event ends a graph segment / launches a collective; with one graph per
         # step (or eager launches without collectives) only in front of the optimizer leg
         lazy_join = not self.collectives and (self.single_graph or not self.use_graphs)
-        for ev in self._step_body(images, text, ssl, rec_images):
-            if not lazy_join or callable(ev) or "FINAL" in ev:
-                self._opt_join()
-            if callable(ev):
+        # this step zeroes the flat gradient buffer and runs every tower's backward exactly once before the optimizer reads it: the
+        # grouped weight-gradient launches may write dW instead of adding to it (engine.Stack.wgrad_overwrite; VTP_WGRAD_OVERWRITE=0: off)
+        stacks = [e.stack for e in (self.trunk, self.decoder, getattr(self, "text", None)) if e is not None and hasattr(e, "stack")]
+        if os.environ.get("VTP_WGRAD_OVERWRITE", "1") not in ("0", "false", "off"):
+            for sk in stacks:
+                sk.wgrad_overwrite = True
+        try:
+            for ev in self._step_body(images, text, ssl, rec_images):
+                if not lazy_join or callable(ev) or "FINAL" in ev:
+                    self._opt_join()
+                if callable(ev):
+                    yield ev
+                    continue
+                keys = [k for k in ev if k != "FINAL"]
+                self._reduced_ranges += merge_ranges([r for k in keys for r in self._bucket_plan[k]])
                 yield ev
-                continue
-            keys = [k for k in ev if k != "FINAL"]
-            self._reduced_ranges += merge_ranges([r for k in keys for r in self._bucket_plan[k]])
-            yield ev
-            if self.overlap_opt and "FINAL" not in ev:
-                self._opt_queue.append(keys)
-                while len(self._opt_queue) >= lag:
-                    self._opt_launch(self._opt_queue.pop(0))
-            elif self.overlap_opt:
-                self._opt_queue.append(keys)  # the last buckets: updated by the body's optimizer leg, on the main stream
+                if self.overlap_opt and "FINAL" not in ev:
+                    self._opt_queue.append(keys)
+                    while len(self._opt_queue) >= lag:
+                        self._opt_launch(self._opt_queue.pop(0))
+                elif self.overlap_opt:
+                    self._opt_queue.append(keys)  # the last buckets: updated by the body's optimizer leg, on the main stream
+        finally:
+            for sk in stacks:
+                sk.wgrad_overwrite = False  # (the autograd boundary shares these engines and must accumulate)
 
     # ---- optimizer lane -----------------------------------------------------------------------------------------------------
     def _opt_plan(self, keys, ema: bool):
