@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="images per CPU-oracle step (the full step costs ~8 s per image on a 128-thread host)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed fp32 steps of the CPU-oracle leg (bf16-autocast leg: half of it)")
+    ap.add_argument("--cpu-survey-protocol", action="store_true", help="SURVEY 8d's CPU protocol: batch 8, 10 timed fp32 steps (5 bf16-autocast) -- "
+                    "about 25 minutes of host time on a 128-thread box, so NOT the default (the driver's run keeps batch 2, 5 + 3 steps)")
     ap.add_argument("--bucket-blocks", type=int, default=3, help="transformer blocks per gradient bucket (= per hipGraph segment / optimizer-lane update)")
     ap.add_argument("--no-lpips-run", action="store_true", help="skip the second measurement with the perceptual term on")
     ap.add_argument("--no-graphs", action="store_true", help="eager kernel launches instead of hipGraph segment replay")
@@ -466,7 +468,15 @@ def main():
         t0 = time.perf_counter()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step spread (one event record per step: free)
         marks[0].record()
+        # VTP_BENCH_THIEF=n (with VTP_DIAG=1; an experiment, never the line of record): a do-nothing kernel holds n CUs on a side stream
+        # for the whole timed region -- the footprint of RCCL's channels beside the step, on one GPU (tools/cu_thief.py)
+        thief_n = int(os.environ.get("VTP_BENCH_THIEF", "0") or 0)
+        if thief_n:
+            from vtp_amd import _lib as _l
+            thief_stream = torch.cuda.Stream()
         for i in range(steps):
+            if thief_n:
+                _l.check(_l.load().vtp_cu_thief(thief_n, 4000000, None, thief_stream.cuda_stream), "vtp_cu_thief")  # 40 ms each, back to back
             loss, closs = one_step(trainer, txt)
             marks[i + 1].record()
         state["host_split_ms"] = [round(v * 1e3 / steps, 3) for v in host_t]
@@ -584,7 +594,7 @@ def main():
                     fh.write(f"{key[0]:14s} M={key[1]:6d} N={key[2]:6d} K={key[3]:6d} epi={key[4]} splits={key[5]:2d}  calls={n:3d}  "
                              f"total={t:7.3f} ms  avg={t / n * 1e3:7.1f} us  {f / t / 1e9:7.1f} TF/s\n")
         traffic, traffic_src, mfma_util, pmc_extra = None, None, None, None
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), "")
         if pmc and args.workload == "vtp_base_full" and not args.batch:
             try:  # HBM bytes per launch and SQ counters of the same kernels from the committed rocprofv3 --pmc passes of this command
                 d = json.load(open(pmc))
@@ -610,6 +620,37 @@ def main():
         # algorithmic HBM bytes of the same launches: every operand read once, every result written once (+ the residual / pre-
         # activation reads of the fused epilogues) -- what `traffic` is to be compared with
         alg = sum(r[4] for r in recs if len(r) > 4 and r[4])
+        # the MIXED floor of the same launches: per launch max(FLOP / dense bf16 MFMA peak, algorithmic bytes / the
+        # 6.3 TB/s a streaming copy achieves) -- what the family would take if every launch sat on whichever roof bounds it
+        HBM_ACHIEVABLE = 6.3e12
+        mixed_ms = sum(max(r[0] / (PEAK_BF16_TFLOPS * 1e12), r[4] / HBM_ACHIEVABLE) for r in recs) * 1e3
+        mfma_ms = sum(r[0] for r in recs) / (PEAK_BF16_TFLOPS * 1e12) * 1e3
+        hbm_bound = sum(1 for r in recs if r[4] / HBM_ACHIEVABLE > r[0] / (PEAK_BF16_TFLOPS * 1e12))
+        # HBM floors of the step's other kernel families from the same counter passes (bytes per step / 6.3 TB/s) beside their kernel
+        # time in the committed rocprofv3 --stats summary of the round (single stream): attention, norms, optimizer lane
+        other = None
+        try:
+            if pmc:
+                d = json.load(open(pmc))
+                rnd = os.path.basename(pmc)[:3]
+                stats = os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_full_eager_b32.csv")
+                tms = {}
+                if os.path.exists(stats):
+                    import csv as _csv
+                    rows_ = list(_csv.DictReader(open(stats)))
+                    nst = max(1, min(int(r_["Calls"]) for r_ in rows_ if "dino_ce_kernel" in r_["Name"])) if any("dino_ce_kernel" in r_["Name"] for r_ in rows_) else 1
+                    for fam in ("attn_fwd", "attn_bwd_fused", "norm_fwd", "norm_bwd", "adamw", "prep_weights"):
+                        tms[fam] = sum(float(r_["TotalDurationNs"]) for r_ in rows_ if fam in r_["Name"]) / nst / 1e6
+                other = {}
+                for fam in ("attn_fwd", "attn_bwd_fused", "norm_fwd", "norm_bwd", "adamw", "prep_weights"):
+                    if fam in d and "FETCH_SIZE" in d[fam]:
+                        steps_pmc = max(1, d["dino_ce"]["FETCH_SIZE"]["dispatches"]) if "dino_ce" in d else 1
+                        byt = 1024.0 * (2.0 * d[fam]["FETCH_SIZE"]["sum"] + d[fam]["WRITE_SIZE"]["sum"]) / steps_pmc
+                        other[fam] = {"hbm_bytes_per_step": round(byt), "hbm_floor_ms": round(byt / HBM_ACHIEVABLE * 1e3, 3),
+                                      "kernel_ms_per_step": round(tms[fam], 3) if fam in tms else None,
+                                      "frac_of_floor": round(byt / HBM_ACHIEVABLE * 1e3 / tms[fam], 3) if tms.get(fam) else None}
+        except (KeyError, ValueError, ZeroDivisionError, OSError):
+            other = None
         roof = {"bound": "mfma", "kernel": "vtp::gemm8p_kernel<...> + vtp::gemm4w_grouped_tn_kernel + vtp::gemm4w_kernel<...> + vtp::gemm8h_kernel<...> + vtp::gemm_nt_kernel<...> (the bf16 MFMA 32x32x16 GEMM family: NT fwd/dgrad, TN wgrad incl. the per-block grouped launches; 256x256 8-phase, one-wave-per-SIMD and 128x256 kernels, ring tile configs, all epilogues)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -621,7 +662,14 @@ def main():
                 "rocprofv3 --pmc pass of this command (profiles/); x sustained clock / 2.4 GHz = fraction of the data-sheet peak",
                 "pmc_by_kernel": pmc_extra, "launches_per_step": len(recs),
                 "avg_launch_us": round(ms * 1e3 / len(recs), 2), "gemm_ms_per_step": round(ms, 3),
-                "flop_per_launch_avg": fl / len(recs)}
+                "flop_per_launch_avg": fl / len(recs),
+                "mixed_floor_ms": round(mixed_ms, 3), "mfma_floor_ms": round(mfma_ms, 3), "frac_of_mixed_floor": round(mixed_ms / ms, 4),
+                "launches_hbm_bound_at_the_floor": hbm_bound,
+                "mixed_floor_note": "sum over the instrumented step's launches of max(2MNK / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s); "
+                "frac_of_mixed_floor = that / gemm_ms_per_step",
+                "other_families_hbm_floor": other,
+                "other_families_note": "bytes per step = 2 x FETCH_SIZE + WRITE_SIZE of the committed --pmc passes (replayed, like `traffic`); "
+                "kernel_ms_per_step from the committed rocprofv3 --stats CSV of the same round (eager, single stream)"}
     if world > 1:
         sync()
 
@@ -720,6 +768,8 @@ def main():
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             e2e = e2e_parity(model, res, dev)  # (before the CPU leg: the model's weights are still on the device)
+            if args.cpu_survey_protocol:
+                args.cpu_batch, args.cpu_steps = 8, 10
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_batch, res, clip, do_ssl, n_fp32=args.cpu_steps, n_bf16=max(1, (args.cpu_steps + 1) // 2))
             out["cpu_baseline"]["e2e_vs_oracle_fp32"] = e2e
         print(json.dumps(out), flush=True)

@@ -81,6 +81,11 @@ int vtp_gemm_tn_grouped_items(const void* probs, int nprob, int ntiles, int K, c
 /* tuning knob (benchmarks / experiments): force a tile configuration id (-1 = heuristic) and toggle the XCD-aware
  * workgroup remap.  Process-global; not part of the reference-facing surface. */
 int vtp_set_gemm_tuning(int force_cfg, int xcd_swizzle);
+/* persistent 256 x 256 NT launches draw their tiles from per-XCD queues in device memory (1) instead of owning a static tile list (0,
+ * default): a launch that cannot get every CU at once -- RCCL channels hold some for the whole backward -- then ends when the tiles
+ * are done, not when the last late-starting workgroup's list is.  Process-global; VTP_GEMM_DYN=0 / 1 in the environment overrides.
+ * VTP_GEMM_CUS=n caps the workgroup slots of every one-workgroup-per-CU GEMM launch (INTEGRATION.md "Running beside RCCL"). */
+int vtp_set_gemm_dynamic(int on);
 /* diagnostics (tools/gemm8p_timeline.py): `timing` = device buffer of [workgroups][16 tiles][4] 64-bit s_memrealtime stamps
  * {tile start, k loop done, epilogue issued} written by the 256x256 kernel (null = off); grid_limit caps its persistent grid
  * (0 = every CU); delay_ticks > 0 starts every second workgroup of an XCD that many 10-ns ticks late (lock-step experiments).
@@ -89,6 +94,9 @@ int vtp_gemm_debug(void* timing, int grid_limit, int delay_ticks);
 /* diagnostics (tools/attn_bwd_timeline.py): `timing` = device buffer of 2 x [workgroups][16 waves][4] 64-bit s_memrealtime stamps
  * {start, operands staged, loop done, gradients stored} written by the resident attention backward kernels (dQ kernel, then the
  * dK/dV kernel), null = off.  Process-global; not part of the reference-facing surface. */
+/* diagnostics (tools/cu_thief.py; VTP_DIAG=1): nwg workgroups that hold one CU each (160 KiB LDS) for ticks x 10 ns on `stream` -- the
+ * footprint of a communication kernel beside the step; out: null or nwg u64 (ticks held) */
+int vtp_cu_thief(int nwg, int ticks, void* out, void* stream);
 int vtp_attn_debug(void* timing, int lds_pad, int waves_per_wg, int stagger_ticks);  /* lds_pad: extra dynamic LDS bytes per workgroup; waves_per_wg: 0 = heuristic */
 /* host-only: the kernel configuration vtp_gemm_nt picks for a shape (8 = 256x256 8-phase, 7 = 128x64 ring tiles, other ids = ring
  * configurations; bits 8.. = in-launch split-K slices when > 1); -1 for a bad shape.  No launch, no device needed. */

@@ -87,3 +87,39 @@ def test_large_512_full_step_gradients():
     _compare_grads("L512 FULL step", dict(c.model.named_parameters()),
                    HEAD_KEYS + TRUNK_KEYS + dec + txt + ["pixel_decoder.proj_out.weight", "trunk.feature_bottleneck.weight",
                                                         "visual_proj.weight", "logit_scale"], c.grads_full)
+
+
+def test_large_512_small_tensors_multi_seed():
+    """The per-tensor statement for the SMALL gradient tensors (< 4096 elements: biases, gains, tokens) at the L-width / 512 x 512
+    geometry, which the single-draw tests above only pool (`dino_head.mlp.4.bias` came out at 1.46 with one seed in
+    profiles/r05_parity.log): the full step on THREE input draws (images, crops, captions, masks), ratio E_ours / E_ref per tensor and
+    draw against BOTH comparators, mean over the draws <= 1.25 against the larger one (the protocol's rule) -- reported against each."""
+    import numpy as np
+    from test_parity_ssl_gpu import SMALL, relF
+    keys = None
+    ratios = {}
+    for si, iseed in enumerate((7, 107, 207)):
+        c = case() if si == 0 else Case(cfg_kw=L2, heads=(16, 16, 16), K=8192, res=512, seed=41, input_seed=iseed)
+        tr, ssl = _trainer(c)
+        tr.step(c.img.to(DEV), c.txt.to(DEV), ssl)
+        torch.cuda.synchronize()
+        params = dict(c.model.named_parameters())
+        G = c.grads_full
+        if keys is None:
+            keys = [k for k in HEAD_KEYS + TRUNK_KEYS if 1 < G["f32"][k].numel() < SMALL]
+            assert "dino_head.mlp.4.bias" in keys
+        for k in keys:
+            e = relF(params[k].grad, G["f32"][k])
+            ec, eg = relF(G["cpu16"][k], G["f32"][k]), relF(G["gpu16"][k], G["f32"][k])
+            ratios.setdefault(k, []).append((e / ec, e / eg, e / max(ec, eg)))
+        if si:
+            del c, tr, ssl, params, G
+            torch.cuda.empty_cache()
+    worst = 0.0
+    for k in keys:
+        r = np.array(ratios[k])
+        print(f"PARITY L512 multi-seed small tensor {k}: per-draw ratios vs the larger comparator {np.round(r[:, 2], 2).tolist()} "
+              f"mean={r[:, 2].mean():.2f} | vs cpu autocast mean={r[:, 0].mean():.2f} | vs cuda autocast mean={r[:, 1].mean():.2f}")
+        worst = max(worst, float(r[:, 2].mean()))
+    print(f"PARITY L512 multi-seed: worst mean ratio over {len(keys)} small tensors = {worst:.2f}")
+    assert worst <= 1.25

@@ -59,7 +59,7 @@ class Case:
     """Seeded VTP-B + DINO head (K = 65536) + EMA teacher, one SSL batch, and the oracle's results in fp32 / CPU autocast /
     CUDA autocast: head outputs, the SSL loss with its gradients, and the full step's loss with its gradients."""
 
-    def __init__(self, cfg_kw=None, heads=(HV, HD, HT), K=65536, res=256, seed=31):
+    def __init__(self, cfg_kw=None, heads=(HV, HD, HT), K=65536, res=256, seed=31, input_seed=7):
         from oracle import vtp_oracle as O
         from vtp_amd import VTP, VTPConfig
         from vtp_amd.data import collate_ssl_masks
@@ -80,12 +80,12 @@ class Case:
         self.sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         self.model = m.to(DEV)
         B = 2
-        g = torch.Generator().manual_seed(7)
+        g = torch.Generator().manual_seed(input_seed)  # (the model is seeded by `seed`; the multi-seed statements vary the INPUTS)
         self.img = torch.randn(B, 3, res, res, generator=g)
-        self.txt = _captions(B, m.config.text_context_length, m.config.text_vocab_size, 8)
+        self.txt = _captions(B, m.config.text_context_length, m.config.text_vocab_size, input_seed + 1)
         self.gc = torch.randn(2 * B, 3, res, res, generator=g)
         self.lc = torch.randn(N_LOCAL * B, 3, 96, 96, generator=g)
-        col = collate_ssl_masks(2 * B, (res // 16, res // 16), 0.5, (0.1, 0.5), np.random.default_rng(11))
+        col = collate_ssl_masks(2 * B, (res // 16, res // 16), 0.5, (0.1, 0.5), np.random.default_rng(input_seed + 4))
         self.col, self.masks = col, col["masks"]
         self.c_d = 0.3 * torch.randn(K, generator=g)
         self.c_i = 0.3 * torch.randn(K, generator=g)
@@ -183,7 +183,9 @@ def _compare_grads(tag, params, keys, G):
             worst, worst_k = r, k
     if pool[4]:
         e, e_ref = (pool[0] / pool[3]) ** 0.5, (max(pool[1], pool[2]) / pool[3]) ** 0.5
-        print(f"PARITY {tag} POOLED {pool[4]} sampled tensors with < {SMALL} elements: E_ours={e:.3e} E_ref={e_ref:.3e} E_ours/E_ref={e / e_ref:.2f}")
+        ec, eg = (pool[1] / pool[3]) ** 0.5, (pool[2] / pool[3]) ** 0.5  # both comparators, not only the larger one
+        print(f"PARITY {tag} POOLED {pool[4]} sampled tensors with < {SMALL} elements: E_ours={e:.3e} E_ref(cpu autocast)={ec:.3e} "
+              f"E_ref(cuda autocast)={eg:.3e} E_ours/E_ref: vs cpu {e / ec:.2f}, vs cuda {e / eg:.2f}, vs the larger (the rule) {e / e_ref:.2f}")
         assert e <= 1.25 * e_ref, f"{tag}: pooled small tensors {e:.3e} > 1.25 x {e_ref:.3e}"
     num = den = ref_c = ref_g = 0.0
     n = 0
@@ -197,8 +199,8 @@ def _compare_grads(tag, params, keys, G):
         ref_g += float((G["gpu16"][k] - g).pow(2).sum())
         n += 1
     e, e_ref = (num / den) ** 0.5, (max(ref_c, ref_g) / den) ** 0.5
-    print(f"PARITY {tag} ALL {n} gradient tensors (flat): E_ours={e:.3e} E_ref={e_ref:.3e} E_ours/E_ref={e / e_ref:.2f}; "
-          f"worst sampled key {worst_k}: {worst:.2f}")
+    print(f"PARITY {tag} ALL {n} gradient tensors (flat): E_ours={e:.3e} E_ref(cpu autocast)={(ref_c / den) ** 0.5:.3e} "
+          f"E_ref(cuda autocast)={(ref_g / den) ** 0.5:.3e} E_ours/E_ref (vs the larger)={e / e_ref:.2f}; worst sampled key {worst_k}: {worst:.2f}")
     assert e <= 1.25 * e_ref
 
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vtp_gemm_nt_config": [_I, _I, _I, _I],
     "vtp_gemm_debug": [_P, _I, _I],
     "vtp_attn_debug": [_P, _I, _I, _I],
+    "vtp_cu_thief": [_I, _I, _P, _P],
+    "vtp_set_gemm_dynamic": [_I],
     "vtp_norm_fwd_e4m3": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "vtp_quantize_e4m3": [_P, _I, _P, _L, _P, _F, _P],
     "vtp_amax": [_P, _I, _L, _P, _P],

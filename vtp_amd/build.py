@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("VTP_BUILD_DIR") or os.path.join(HERE, "lib")  # VTP_BUILD_DIR: a second build (A/B of -D switches, loaded with VTP_HIP_LIB)
 LIB = os.path.join(LIBDIR, "libvtp_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-ffp-contract=on", "-I", CSRC, "-I",

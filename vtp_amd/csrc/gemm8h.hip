@@ -314,6 +314,7 @@ static int launch8h(const GemmArgs& a, hipStream_t s) {
     (void)hipGetDeviceProperties(&prop, dev);
     int cus = prop.multiProcessorCount - prop.multiProcessorCount % 8;
     if (cus < 8) cus = 8;
+    cus = gemm_cu_cap(cus);
     slots = 2 * cus;  // two resident workgroups per CU
     if (const char* e = getenv("VTP_GEMM8H_WG_PER_CU")) slots = atoi(e) > 0 ? atoi(e) * cus : slots;  // diagnostics
     if (getenv("VTP_GEMM8H_DEBUG")) {

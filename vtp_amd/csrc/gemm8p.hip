@@ -90,7 +90,19 @@ struct GroupTile {
   int tile, splits;
 };
 
-template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
+// DYN (persistent NT launches, one K slice, >= 3 k-tiles per tile): the workgroup does not own tiles bx, bx + G, ... but DRAWS them
+// from per-XCD queues in device memory (p.tq: heads of 8 queues that hold the same contiguous chunks of the tile list as the static
+// XCD-aware order; the workgroup draws from queue bx & 7).  A launch that cannot get all of its CUs at once -- an RCCL kernel holds
+// 16 .. 32 of them for the whole backward, or another stream's GEMM is still running -- then ends when the TILES are done, not when
+// the statically-assigned tile list of a late-starting workgroup is (tools/cu_thief.py).  The staging cursor runs into the next tile
+// 1.75 k-tiles ahead of the MFMAs, so a workgroup holds TWO tiles beyond the one it computes: tiles 0 and 1 come from one blocking
+// fetch_add(2) at the start; tile i + 2 is drawn by thread 0 at the START of tile i's epilogue (an ordinary compiler-visible atomic:
+// the epilogue's own loads drain the vector-memory queue anyway), goes into an LDS mailbox at its END and is taken into an SGPR by
+// every wave at k-tile 1 of tile i + 1 -- before the cursor needs it (k-tile nk - 2).  (A returning atomic from inline asm inside the
+// k loop was tried first: its destination register is written when the result arrives, long after the statement, and the compiler
+// -- which cannot know -- had meanwhile given the register to something else: memory faults.)  The last workgroup to leave zeroes the
+// queue words.
+template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0, bool DYN = false>
 __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslice, const int G, const bool flat, const GroupTile gt) {
   // VAR bit 3: the operands are fp8 (e4m3, OCP) -- same bytes, same staging, same fragment reads (the launcher passes K and the
   // leading dimensions in 2-byte units); only the MFMA changes: v_mfma_f32_32x32x64_f8f6f4 takes 32 B per lane, i.e. two of
@@ -107,20 +119,58 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   const int tiles_n = (p.N + 255) >> 8;
   const int ntiles = tiles_m * tiles_n;
   // (bx, zslice, G): this workgroup computes tiles bx, bx + G, ... of K slice zslice (the kernels below derive them from the grid)
-  const int n_my = (ntiles - bx + G - 1) / G;
+  const int n_my = DYN ? 0x10000 : (ntiles - bx + G - 1) / G;
+  // DYN: queue bx & 7 = positions [q_start, q_start + q_n) of the tile list; d_cur = position being computed, d_next = the one the
+  // staging cursor moves to next (-1: none), all wave-uniform
+  int q_start = 0, q_n = 0, d_cur = -1, d_next = -1;
+  bool d_more = DYN;      // the last draw returned a tile: keep drawing
+  bool d_mail = false;    // the previous tile's epilogue left a draw in the mailbox
+  int* const d_head = DYN ? p.tq + (bx & 7) * 16 : nullptr;
+  if constexpr (DYN) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = bx & 7;
+    q_n = q + (x < r ? 1 : 0);
+    q_start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  }
+  auto pos_origin = [&](int wg, int& m0, int& n0) {
+    n0 = (wg % tiles_n) << 8;
+    m0 = (wg / tiles_n) << 8;
+  };
   auto tile_origin = [&](int i, int& m0, int& n0) {
     int wg = bx + i * G;
     if ((p.xcd_swizzle & 1) && !flat) {  // bijective on [0, ntiles): XCD x owns a contiguous chunk of the tile list
       const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
       wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
     }
-    n0 = (wg % tiles_n) << 8;
-    m0 = (wg / tiles_n) << 8;
+    pos_origin(wg, m0, n0);
   };
+  auto tq_exit = [&]() {  // once per workgroup, behind its last draw: the last one to leave resets the queue words for the next launch
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(p.tq + 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == G - 1) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) __hip_atomic_store(p.tq + 16 * x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.tq + 128, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int* const mbox = (int*)(smem + P8_RING);  // DYN: mailbox word (the epilogue staging area is idle during the k loops)
+  if constexpr (DYN) {  // the first two tiles: one blocking draw of two consecutive queue positions
+    if (tid == 0) *mbox = __hip_atomic_fetch_add(d_head, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int j = __builtin_amdgcn_readfirstlane(*(volatile int*)mbox);
+    __syncthreads();
+    if (j >= q_n) {
+      tq_exit();
+      return;
+    }
+    d_cur = q_start + j;
+    d_more = j + 1 < q_n;
+    d_next = d_more ? d_cur + 1 : -1;
+  }
   const int kbeg = zslice * p.k_split;
   const int kend = min(p.K, kbeg + p.k_split);
   const int nk = (kend - kbeg + 63) >> 6;
-  const int H = n_my * nk * 4;  // half-tiles this workgroup streams
+  const int H = n_my * nk * 4;  // half-tiles this workgroup streams (DYN: unknown -- the cursor stops when a draw comes back empty)
 
   // ---------------------------------------------------------------- staging (LDS-DMA) side
   const char* zsrc = (const char*)g_zero_block;
@@ -171,6 +221,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   // of scalar instructions: half-tile counter, my-tile index, k-tile inside that tile, LDS destination of this wave's piece 0
   // of the half-tile under the cursor, the operand bases advanced to the cursor's k-tile, "no K tail in this k-tile"
   int s_h = 0, s_i = 0, s_kt = 0;
+  bool s_stop = false;  // DYN: the tile under the cursor was the last one
   unsigned s_dst = (unsigned)(size_t)smem + wave * 2048;
   const size_t step_a = TRANS ? (size_t)128 * p.lda : 128, step_b = TRANS ? (size_t)128 * p.ldb : 128;
   const char* s_pa = (const char*)p.A;
@@ -201,7 +252,15 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         s_kt = 0;
         s_pa = (const char*)p.A;
         s_pb = (const char*)p.B;
-        if (++s_i < n_my) {
+        if constexpr (DYN) {
+          if (d_next >= 0) {
+            int m0s, n0s;
+            pos_origin(d_next, m0s, n0s);
+            set_src(m0s, n0s);
+          } else {
+            s_stop = true;  // no further tile: the cursor stops (s_h stays the true count of half-tiles issued: the vmcnt waits use it)
+          }
+        } else if (++s_i < n_my) {
           int m0s, n0s;
           tile_origin(s_i, m0s, n0s);
           set_src(m0s, n0s);
@@ -331,16 +390,17 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   // ---------------------------------------------------------------- prologue: 7 half-tiles in flight, the first 4 landed
   {
     int m0s, n0s;
-    tile_origin(0, m0s, n0s);
+    if constexpr (DYN) pos_origin(d_cur, m0s, n0s);
+    else tile_origin(0, m0s, n0s);
     set_src(m0s, n0s);
   }
-  if (s_h < H) issue(I0{});
-  if (s_h < H) issue(I1{});
-  if (s_h < H) issue(I2{});
-  if (s_h < H) issue(I3{});
-  if (s_h < H) issue(I0{});
-  if (s_h < H) issue(I1{});
-  if (s_h < H) issue(I2{});
+  if (DYN ? !s_stop : s_h < H) issue(I0{});
+  if (DYN ? !s_stop : s_h < H) issue(I1{});
+  if (DYN ? !s_stop : s_h < H) issue(I2{});
+  if (DYN ? !s_stop : s_h < H) issue(I3{});
+  if (DYN ? !s_stop : s_h < H) issue(I0{});
+  if (DYN ? !s_stop : s_h < H) issue(I1{});
+  if (DYN ? !s_stop : s_h < H) issue(I2{});
   p8_wait_vm_halftiles(s_h - 4);
   seg_barrier();
 
@@ -356,7 +416,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
   };
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
-    tile_origin(ti, m0, n0);
+    if constexpr (DYN) pos_origin(d_cur, m0, n0);
+    else tile_origin(ti, m0, n0);
     stamp(ti, 0);
     if constexpr (TRANS) do_csum = p.colsum != nullptr && wc == 0 && n0 == 0;
     if (wr == 1) seg_barrier();  // group 1 runs one barrier behind group 0 through this tile's k loop
@@ -365,6 +426,12 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
         p.timing[(size_t)(gridDim.x + blockIdx.x) * 64 + kt] = wall_clock64();
       const char* kb = smem + (ktg & 1) * (4 * P8_SLOT);
       Frags b1, b2, a1[2], a2[2];
+      if constexpr (DYN) {
+        if (kt == 1 && d_mail) {  // written by thread 0 at the end of the previous epilogue: every wave is >= 4 barriers past that
+          d_next = __builtin_amdgcn_readfirstlane(*(volatile int*)mbox);
+          d_more = d_next >= 0;
+        }
+      }
 #ifndef VTP_P8_FOUR_PHASE
       // Two phases of 16 MFMAs per k-tile (the schedule in use since round 4: half as many barrier intervals per k-tile as the four
       // phases of 8 MFMAs below; measured 1-3 % per launch, +0.3 % on the step in three of three same-box repetitions,
@@ -374,7 +441,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       load_a(kb + P8_SLOT, a1);
       load_b(kb + 2 * P8_SLOT, b2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I3{});
+      if (DYN ? !s_stop : s_h < H) issue(I3{});
       __builtin_amdgcn_sched_barrier(0);
       p8_wait_vm_halftiles(s_h - 4 * ktg - 4);  // A-second of THIS k-tile (read in phase B)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // phase B overwrites the three slots read here
@@ -388,9 +455,9 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       // ---- phase B: A-second -> quadrants (cols 0..63, rows 64..127); issues B-first, A-first, B-second of the k-tile after next
       load_a(kb + 3 * P8_SLOT, a2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I0{});
-      if (s_h < H) issue(I1{});
-      if (s_h < H) issue(I2{});
+      if (DYN ? !s_stop : s_h < H) issue(I0{});
+      if (DYN ? !s_stop : s_h < H) issue(I1{});
+      if (DYN ? !s_stop : s_h < H) issue(I2{});
       __builtin_amdgcn_sched_barrier(0);
       p8_wait_vm_halftiles(s_h - 4 * ktg - 7);  // B-first, A-first, B-second of the NEXT k-tile (read in its phase A)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next phase A overwrites the slot read here
@@ -403,12 +470,13 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       seg_barrier();
     }
 #else
+      static_assert(!DYN, "the tile queue is wired into the two-phase schedule only");
       // ---- phase 0: B-first + A-first -> quadrant (cols 0..31, rows 0..63)
       load_b(kb, b1);
       __builtin_amdgcn_sched_barrier(0);
       load_a(kb + P8_SLOT, a1);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I3{});
+      if (DYN ? !s_stop : s_h < H) issue(I3{});
       __builtin_amdgcn_sched_barrier(0);
       // the B-first reads (issued first) are done: phase 1 overwrites that slot (TN: 8 + 16 tr reads, the counter holds 15)
       if constexpr (!TRANS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -422,14 +490,14 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63)
       load_b(kb + 2 * P8_SLOT, b2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I0{});
+      if (DYN ? !s_stop : s_h < H) issue(I0{});
       seg_barrier();
       mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
       seg_barrier();
       // ---- phase 2: A-second -> quadrant (cols 32..63, rows 64..127)
       load_a(kb + 3 * P8_SLOT, a2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I1{});
+      if (DYN ? !s_stop : s_h < H) issue(I1{});
       seg_barrier();
       mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
       if constexpr (TRANS) {
@@ -437,7 +505,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
       }
       seg_barrier();
       // ---- phase 3: quadrant (cols 0..31, rows 64..127); the next k-tile's four half-tiles must have landed
-      if (s_h < H) issue(I2{});
+      if (DYN ? !s_stop : s_h < H) issue(I2{});
       p8_wait_vm_halftiles(s_h - 4 * (ktg + 2));
       seg_barrier();
       mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
@@ -526,10 +594,28 @@ __device__ __forceinline__ void gemm8p_body(const GemmArgs& p, int bx, int zslic
     // the ring slot under the staging cursor is free (its half-tile was consumed >= 2 phases ago, the next LDS-DMA into it is issued
     // after this epilogue): the wave's own 2 KiB of it are a second staging region
     char* reg2 = (EPI == EPI_SWIGLU && reg) ? smem + s_dst : nullptr;
+    int d_t = 0;
+    if constexpr (DYN) {  // the tile after next
+      if (d_more && tid == 0) d_t = __hip_atomic_fetch_add(d_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     gemm_epilogue<EPI, TRANS, 128, 64, P8_REGION, XMODE>(p, acc, reg, m0, n0, wr, wc, lane, zslice, reg2);
     stamp(ti, 2);
     zero_acc();
+    if constexpr (DYN) {
+      d_mail = d_more;
+      if (d_more && tid == 0) *(volatile int*)mbox = d_t < q_n ? q_start + d_t : -1;
+      d_cur = d_next;
+      d_next = -1;  // (known at k-tile 1 of the next tile, if a draw is in the mailbox)
+      if (d_cur < 0) break;
+    }
   }
+  if constexpr (DYN) tq_exit();
+}
+
+// the persistent NT launch with dynamic tile assignment (gemm8p_body<.., DYN = true>): grid = the CU count, one K slice
+template <int EPI, int VAR = 0, int XMODE = 0>
+__global__ __launch_bounds__(512) void gemm8p_dyn_kernel(const GemmArgs p) {
+  gemm8p_body<EPI, false, VAR, XMODE, true>(p, blockIdx.x, 0, (int)gridDim.x, false, GroupTile{nullptr, nullptr, 0, 1});
 }
 
 template <int EPI, bool TRANS, int VAR = 0, int XMODE = 0>
@@ -624,6 +710,47 @@ static CombineScratch* combine_scratch(hipStream_t s) {
   return &pool[it->second];
 }
 
+// queue words of the dynamic tile assignment (GemmArgs::tq): 256 ints per stream (heads of the 8 per-XCD queues 64 B apart, the exit
+// counter), zero between launches.  Launches on one stream are serialised and share a slot; every stream handle is bound to its own
+// slot the first time it is seen.  The pool (64 slots) is allocated at the first persistent launch outside stream capture (the trainers
+// warm up eagerly); no pool / no free slot: the launch keeps the static tile lists.
+static int* tile_queue(hipStream_t s) {
+  constexpr int SLOTS = 64;
+  static std::mutex mu;
+  static int* pool = nullptr;
+  static std::unordered_map<hipStream_t, int> slot_of;
+  static bool failed = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool) {
+    if (failed) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    if (hipMalloc((void**)&pool, (size_t)SLOTS * 256 * sizeof(int)) != hipSuccess || hipMemset(pool, 0, (size_t)SLOTS * 256 * sizeof(int)) != hipSuccess) {
+      pool = nullptr;
+      failed = true;
+      return nullptr;
+    }
+  }
+  auto it = slot_of.find(s);
+  if (it == slot_of.end()) {
+    if ((int)slot_of.size() >= SLOTS) return nullptr;
+    it = slot_of.emplace(s, (int)slot_of.size()).first;
+  }
+  return pool + it->second * 256;
+}
+
+// dynamic tile assignment of the persistent launches: VTP_GEMM_DYN=0 / 1 in the environment wins; otherwise what vtp_set_gemm_dynamic
+// asked for (the trainers turn it on when they run beside collectives); default off -- on a chip the step has to itself the static
+// lists are 0.4 % faster (no draw at the start of a workgroup, no exit count: 702 vs 699 images/s, profiles/r06_dyn_tiles.log)
+static int g_dyn_mode = 0;
+static bool gemm_dyn_enabled() {
+  static int env = -2;
+  if (env == -2) {
+    const char* e = getenv("VTP_GEMM_DYN");
+    env = e ? (e[0] == '0' ? 0 : 1) : -1;
+  }
+  return env >= 0 ? env == 1 : g_dyn_mode == 1;
+}
 // may this stream use the in-launch split-K combine?  (allocates the scratch pool at the first call outside stream capture; false:
 // the dispatcher launches the shape unsplit)
 bool gemm8p_combine_ready(hipStream_t s) { return combine_scratch(s) != nullptr; }
@@ -666,7 +793,24 @@ static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(512), P8_LDS, s, f);
     return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
   }
-  const int cap = g_p8_grid > 0 ? g_p8_grid : cus;
+  const int cap = g_p8_grid > 0 ? g_p8_grid : gemm_cu_cap(cus);
+  if constexpr (!TRANS && EPI != EPI_F32_SLAB && EPI != EPI_F32_ATOMIC) {
+    // persistent launch: tiles drawn from per-XCD queues (gemm8p_body DYN) when the shape allows the look-ahead (>= 4 k-tiles per tile)
+    if (splits == 1 && ntiles > cap && a.K >= 256 && (a.xcd_swizzle & 1) && !a.timing && gemm_dyn_enabled()) {
+      int* tq = tile_queue(s);
+      if (tq) {
+        auto dk = gemm8p_dyn_kernel<EPI, VAR, XMODE>;
+        static bool dattr = false;
+        if (!dattr) {
+          hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+          dattr = true;
+        }
+        a.tq = tq;
+        hipLaunchKernelGGL(dk, dim3(cap), dim3(512), P8_LDS, s, a);
+        return check_launch("gemm8p_nt_dyn");
+      }
+    }
+  }
   dim3 grid(splits == 1 && ntiles > cap ? cap : ntiles, 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS, s, a);
   return check_launch(TRANS ? "gemm8p_tn" : "gemm8p_nt");
@@ -766,6 +910,11 @@ extern "C" int vtp_gemm_tn_grouped_items(const void* probs, int nprob, int ntile
 extern "C" int vtp_gemm_tn_grouped(const void* probs, int nprob, int ntiles, int K, int splits, void* part, void* ticket,
                                    void* stream) {
   return vtp_gemm_tn_grouped_k(probs, nprob, ntiles, K, splits, part, ticket, 0, stream);
+}
+
+extern "C" int vtp_set_gemm_dynamic(int on) {
+  vtp::g_dyn_mode = on ? 1 : 0;
+  return VTP_OK;
 }
 
 // diagnostics for tools/gemm8p_timeline.py: `timing` = device buffer of [workgroups][16 tiles][4] u64 s_memrealtime stamps (100 MHz)

@@ -1,6 +1,7 @@
 // Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: ring / 2-barrier main loops; gemm8p.hip: 256x256 8-phase main loop):
 // the argument block, the row remaps and the fused epilogues.  Device code only.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include "vtp_hip.h"
 
@@ -49,11 +50,31 @@ struct GemmArgs {
   // one arrival ticket per tile; null: off.  Set by the launcher (per-stream scratch), never by callers.
   float* part;
   int* ticket;
+  // dynamic tile assignment of the persistent 256 x 256 kernels (round 6): per-stream queue words in device memory -- heads of the 8
+  // per-XCD tile queues at tq[16 x], the exit counter at tq[128] (all zero between launches); null: tiles are dealt statically.
+  // Set by the launcher, never by callers.
+  int* tq;
   // diagnostics (vtp_gemm_debug): per workgroup and tile, s_memrealtime stamps {tile start, k loop done, epilogue issued}; null = off
   unsigned long long* timing;
   int dbg_delay;  // diagnostics: > 0: every second workgroup (per XCD) starts this many 10-ns ticks late (lock-step experiments)
 };
 
+// VTP_GEMM_CUS=n (read once): the persistent kernels launch n workgroup slots instead of one per CU (rounded down to a multiple of 8)
+// -- leaves CUs to a kernel that holds them for the whole backward (RCCL channels at N > 1; INTEGRATION.md "Running beside RCCL")
+static inline int gemm_cu_cap(int cus) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VTP_GEMM_CUS");
+    v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+  }
+  if (v >= 8 && v < cus) return v - v % 8;
+  return cus;
+}
+
+#ifndef VTP_EPI_F32_PF
+#define VTP_EPI_F32_PF 1  // residual rows requested this many LDS passes ahead in the staged fp32 epilogue (A/B builds: -DVTP_EPI_F32_PF=1)
+#endif
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32_ATOMIC = 4, EPI_F32_SLAB = 5, EPI_CONV_RELU = 6,
        EPI_CONV_MASK = 7 };
 
@@ -350,7 +371,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
       // the residual rows of pass k + 1 are requested before pass k goes through LDS (they are then OLDER than pass k's stores in the
       // in-order VMEM queue: waiting for them does not wait for those stores): one HBM round trip per tile is exposed instead of one
       // per pass (the dominant cost of this epilogue at K = 768: 8 dependent round trips per 256x256 tile)
-      f32x4 rv[2][T];
+      // PF passes ahead (round 6: 1 -> 2; with one pass ahead a wave had 4 KiB of residual rows in flight and the tile's NPASS
+      // dependent round trips -- not bandwidth -- set the length of this epilogue: tools/wgrad_timeline.py, 38 us per 256 x 256 tile)
+      constexpr int PF = VTP_EPI_F32_PF;
+      f32x4 rv[PF + 1][T];
       auto coords = [&](int pass, int t, int& m, int& n) {
         const int j = pass / (TN / IG), ig = pass % (TN / IG);
         const int idx = t * 64 + lane, rr = idx / CPR, c = idx % CPR;
@@ -366,7 +390,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           if (p.resid && m < p.M && n < p.N) dst[t] = *(const f32x4*)(p.resid + (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n);
         }
       };
-      fetch(0, rv[0]);
+#pragma unroll
+      for (int f = 0; f < PF; ++f)
+        if (f < NPASS) fetch(f, rv[f]);
       // bias / LayerScale values of the lane's columns: the column of item t is the same for every t and row block (64 % CPR == 0),
       // so they are loaded once per column group instead of inside every pass
       static_assert(64 % CPR == 0, "a lane's column must not depend on t");
@@ -380,7 +406,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         const int j = pass / (TN / IG), ig = pass % (TN / IG);
-        if (pass + 1 < NPASS) fetch(pass + 1, rv[(pass + 1) & 1]);
+        if (pass + PF < NPASS) fetch(pass + PF, rv[(pass + PF) % (PF + 1)]);
 #pragma unroll
         for (int ii = 0; ii < IG; ++ii)
 #pragma unroll
@@ -398,7 +424,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[W
           coords(pass, t, m, n);
           if (m < p.M && n < p.N) {
             const size_t off = (size_t)remap_row(m, p.c_grp, p.c_pre) * p.ldc + n;
-            v = (v + bs[ig]) * gm[ig] + rv[pass & 1][t];
+            v = (v + bs[ig]) * gm[ig] + rv[pass % (PF + 1)][t];
             *(f32x4*)((float*)p.C + off) = v;
           }
         }

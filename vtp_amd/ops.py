@@ -171,10 +171,21 @@ def wgrad_group_fits(Ktok: int, max_ld: int) -> bool:
     return int(Ktok) * int(max_ld) * 2 < (1 << 32)
 
 
+def gemm_cus() -> int:
+    """workgroup slots the one-workgroup-per-CU GEMM launches may use: 256, or VTP_GEMM_CUS (the library's persistent kernels read the
+    same variable) when CUs are to be left to a long-running communication kernel (INTEGRATION.md "Running beside RCCL")"""
+    import os
+    try:
+        v = int(os.environ.get("VTP_GEMM_CUS", "0") or 0)
+    except ValueError:
+        v = 0
+    return v - v % 8 if 8 <= v < 256 else 256
+
+
 def wgrad_group_splits(ntiles: int, Ktok: int):
-    """split rule of a grouped launch: tiles x splits fills one round of the 256 CUs, every K slice keeps >= 16 k-tiles; returns
-    (k rows per slice, effective slice count) -- the launcher (vtp_gemm_tn_grouped) rounds the same way"""
-    s = max(1, min(256 // ntiles, Ktok // 1024))
+    """split rule of a grouped launch: tiles x splits fills one round of the CUs (256, or VTP_GEMM_CUS), every K slice keeps >= 16
+    k-tiles; returns (k rows per slice, effective slice count) -- the launcher (vtp_gemm_tn_grouped) rounds the same way"""
+    s = max(1, min(gemm_cus() // ntiles, Ktok // 1024))
     ks = ((Ktok + s - 1) // s + 63) // 64 * 64
     return ks, (Ktok + ks - 1) // ks
 
@@ -193,7 +204,7 @@ def wgrad_group_kernel(ntiles: int, splits: int, Ktok: int) -> int:
     return 1 if Ktok // max(splits, 1) >= W4_TN_MIN_SLICE else 0
 
 
-def wgrad_group_items(rows, Ktok: int, base_splits: int, cus: int = 256):
+def wgrad_group_items(rows, Ktok: int, base_splits: int, cus: int = None):
     """work-item list of a grouped launch on the one-wave-per-SIMD kernel (vtp_gemm_tn_grouped_items).  rows: the GroupProblem records
     (WgradGroup.rows).  Every tile is cut into `base_splits` K ranges, except the tiles that also form a bias gradient -- the first tile
     column of a problem with a colsum target: their k loop carries 64 v_dot2 per k-tile beside its 64 MFMAs and measures 27 % slower
@@ -201,6 +212,8 @@ def wgrad_group_items(rows, Ktok: int, base_splits: int, cus: int = 256):
     and the shorter slice keeps >= 16 k-tiles.  Returns (items [n, 8] int32 rows {tile, kbeg, kcount, nparts, part, 0, 0, 0}, slots).
     Order: per problem, the heavier-cut tiles first, slice-major inside a group -- the kernel deals contiguous chunks of the list to
     the XCDs, so the workgroups that stream the same K range of the same operand panels sit behind one L2."""
+    cus = gemm_cus() if cus is None else cus
+
     def cuts(n):
         ks = ((Ktok + n - 1) // n + 63) // 64 * 64
         return [(b, min(Ktok, b + ks) - b) for b in range(0, Ktok, ks)]

@@ -358,6 +358,11 @@ class VTPTrainer:
         self._head_stream, self._head_keys = None, []
         self._works_prev = []  # (work, after) pairs of the previous bucket event's reductions (_handle)
         self.collectives = self.bucketer.active  # world > 1, or a one-rank group with force_collectives
+        if self.collectives:
+            # RCCL's channels hold CUs while the backward runs: the persistent GEMMs draw their tiles instead of owning static lists
+            # (csrc/gemm8p.hip DYN; tools/cu_thief.py: a chain of the step's GEMMs beside 32 held CUs x1.02 instead of x1.18)
+            from . import _lib
+            _lib.load().vtp_set_gemm_dynamic(1)
         self.time_comm = False       # bench: record HIP events around every point where the main stream waits for RCCL
         self._comm_events = []
         self.world, self.rank, self.group = self.bucketer.world, self.bucketer.rank, group
