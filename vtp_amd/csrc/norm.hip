@@ -3,6 +3,7 @@
 //   bwd:  dx f32 = dres + d(norm)/dx ;  dw/db accumulated with one atomicAdd per column per workgroup.
 // Rows are read as float4 per lane (16 B), row-resident in registers (D <= 2048).
 #include "common.h"
+#include <cstdlib>
 #include "vtp_hip.h"
 
 namespace vtp {
@@ -246,7 +247,17 @@ extern "C" int vtp_norm_bwd(const void* dy, const float* x, const float* w, cons
   VTP_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= NORM_MAXC * 256, "vtp_norm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
   VTP_REQUIRE(kind == 0 || kind == 1, "vtp_norm_bwd: kind must be 0 or 1");
   int blocks = cdiv(M, D <= 768 ? 8 : 4);
-  if (blocks > 1024) blocks = 1024;
+  // every block ends with one atomic per column and target (dw, db, the column sums of dx): with 1024 blocks that is 1024 adds queued on
+  // each of ~2 300 addresses, ~11 us of serialised atomics -- a third of the launch at 8 192 rows.  Fewer, longer-running blocks
+  // (tools/norm_bench.py, round 6): 8 192 rows 39.0 -> 25.0 us (256 blocks), 16 448 rows 45.1 -> 39.1, 34 144 rows 87.2 -> 83.7 (512;
+  // 256 blocks no longer keep enough loads in flight there), 2 464 rows 15.4 -> 13.3 (128).  VTP_NORM_BWD_BLOCKS=n overrides.
+  static int cap_env = -1;
+  if (cap_env < 0) {
+    const char* e = getenv("VTP_NORM_BWD_BLOCKS");
+    cap_env = e && atoi(e) > 0 ? atoi(e) : 0;
+  }
+  const int cap = cap_env ? cap_env : (M >= 24576 ? 512 : (M >= 4096 ? 256 : 128));
+  if (blocks > cap) blocks = cap;
   dim3 grid(blocks), block(256);
   if (kind == 0)
     NORM_DISPATCH(norm_bwd_kernel, 0, (const bf16*)dy, x, w, stats, dres, dx, (bf16*)dx_bf16, dw, db, dx_colsum, M, D);
