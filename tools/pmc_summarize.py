@@ -11,7 +11,7 @@ from collections import defaultdict
 def family(name: str) -> str:
     name = re.sub(r"^void ", "", name)
     m = re.match(r"(?:vtp::)?(\w+)", name.replace("_ZN3vtp", ""))
-    if "gemm4w_grouped_tn_kernel" in name:
+    if "gemm4w_grouped_tn" in name:  # (..._kernel: uniform tiles x slices; ..._items_kernel: the work-item list of round 6)
         return "gemm4w_grouped_tn"
     if "gemm4w_kernel" in name:
         return "gemm4w_nt"
@@ -19,6 +19,8 @@ def family(name: str) -> str:
         return "gemm8p_grouped_tn"
     if "gemm8h_kernel" in name:
         return "gemm8h_nt"
+    if "gemm8p_dyn_kernel" in name:  # the persistent NT launch with tiles drawn from queues (round 6)
+        return "gemm8p_nt"
     if "gemm8p_kernel" in name:
         return "gemm8p_tn" if re.search(r"gemm8p_kernel<\d+, true", name) else "gemm8p_nt"
     if "gemm_nt_kernel" in name:
