@@ -622,3 +622,6 @@ def test_wgrad_group_item_list_partitions_every_tile():
         assert heavy == (ncs if fits else 0) and len(items) <= max(256, ntiles * base), (D, Ktok, heavy, ncs, len(items))
         if (D, Ktok) == (768, 34144):
             assert (base, slots, len(items)) == (2, 3, 241)
+            # planned for fewer CUs (VTP_GEMM_CUS = 240 beside RCCL's channels): 241 workgroups no longer fit one round -> the uniform cut
+            items2, slots2 = wgrad_group_items(rs, Ktok, base, cus=240)
+            assert (slots2, len(items2)) == (2, 216)
