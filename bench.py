@@ -372,11 +372,11 @@ def main():
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")  # a timed-out collective tears the process down (no hang)
         # RCCL's channels are workgroups that hold a CU each while a collective runs, and the step's one-workgroup-per-CU GEMMs (160 KiB
         # of LDS) cannot share a CU with them: a launch that needs every CU then takes a second round.  The step's gradient traffic (1.28 GB
-        # in ~35 ms of backward) needs ~65 GB/s, so a few channels are plenty: cap RCCL at 16 and leave those 16 CUs out of the GEMM grids
-        # (2 CUs of 32 per XCD; the cap itself costs < 1 % -- 224 of 256 CUs cost 1.5 %, profiles/r06_dyn_tiles.log).  Both only as
+        # in ~35 ms of backward) needs ~65 GB/s, so half of RCCL's usual channel count is plenty: cap it at 32 and leave those 32 CUs out of the
+        # GEMM grids (4 CUs of 32 per XCD; 224 of 256 CUs cost the step 1.5 % when nothing else runs, profiles/r06_dyn_tiles.log).  Both only as
         # defaults: the environment of the launch wins.  INTEGRATION.md "Running beside RCCL".
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
-        os.environ.setdefault("VTP_GEMM_CUS", "240")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+        os.environ.setdefault("VTP_GEMM_CUS", "224")
         tmo = datetime.timedelta(seconds=args.dist_timeout)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
