@@ -1,5 +1,6 @@
-"""Dynamic tile assignment of the persistent 256 x 256 NT GEMM (vtp_amd/csrc/gemm8p.hip, gemm8p_body<.., DYN>: workgroups DRAW their tiles
-from per-XCD queues in device memory instead of owning the static list bx, bx + G, ...; vtp_set_gemm_dynamic).  Which workgroup computes
+"""Dynamic tile assignment of the persistent NT GEMMs (vtp_amd/csrc/gemm8p.hip gemm8p_body<.., DYN>, and the same queues in gemm8h.hip /
+gemm4w.hip: workgroups DRAW their tiles from per-XCD queues in device memory instead of owning the static list bx, bx + G, ...;
+vtp_set_gemm_dynamic).  Which workgroup computes
 a tile cannot change a single bit of it -- every comparison is BIT FOR BIT against the static launch: every epilogue of the step, ragged
 M tails, launches back to back on one stream (the queue words must be back at zero), on two streams at once (one queue slot per
 stream), and with CUs taken away while the launch runs (a do-nothing kernel holds 32 of them: the case the mechanism exists for)."""
@@ -56,14 +57,17 @@ def _launchers(M, N, K, kind, g):
     return run, outs
 
 
-SHAPES = [(34144, 768, 768, "f32res"), (34144, 2304, 768, "rope"), (34144, 4096, 768, "swiglu"), (34144, 768, 2048, "f32res"),
-          (34144, 768, 768, "bf16"), (16448, 2304, 768, "bf16"), (70001, 768, 256, "bf16"), (33000, 1536, 320, "gelu")]
+SHAPES = [(8, 34144, 768, 768, "f32res"), (8, 34144, 2304, 768, "rope"), (8, 34144, 4096, 768, "swiglu"), (8, 34144, 768, 2048, "f32res"),
+          (8, 34144, 768, 768, "bf16"), (8, 16448, 2304, 768, "bf16"), (8, 70001, 768, 256, "bf16"), (8, 33000, 1536, 320, "gelu"),
+          # the half-size kernel (two workgroups per CU: 512 slots) and the one-wave-per-SIMD kernel, forced
+          (9, 34144, 2304, 768, "rope"), (9, 34144, 2048, 768, "bf16"), (9, 34144, 4096, 768, "swiglu"), (9, 70001, 768, 768, "f32res"),
+          (9, 40000, 1024, 192, "bf16"), (10, 34144, 768, 4096, "bf16"), (10, 34144, 768, 2304, "bf16"), (10, 70001, 512, 2048, "bf16")]
 
 
-@pytest.mark.parametrize("M,N,K,kind", SHAPES)
-def test_dynamic_tiles_bit_identical_to_static(M, N, K, kind):
+@pytest.mark.parametrize("cfg,M,N,K,kind", SHAPES)
+def test_dynamic_tiles_bit_identical_to_static(cfg, M, N, K, kind):
     from vtp_amd import _lib
-    _lib.load().vtp_set_gemm_tuning(8, 3)  # the 256 x 256 kernel for every shape (the dispatch would send some to other kernels)
+    _lib.load().vtp_set_gemm_tuning(cfg, 3)  # one kernel for the shape (the dispatch would send it where it measured best)
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     run, outs = _launchers(M, N, K, kind, g)
     _dyn(False)

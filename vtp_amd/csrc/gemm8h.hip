@@ -89,7 +89,13 @@ struct H8Frags {
   bf16x8 f[4];
 };
 
-template <int EPI, int XMODE>
+int* gemm_tile_queue(hipStream_t s);  // gemm8p.hip: per-stream queue words of the dynamic tile assignment
+bool gemm_dyn_enabled();
+
+// DYN: tiles drawn from the per-XCD queues of p.tq instead of the static list bx, bx + G, ... -- the protocol of gemm8p_body<.., DYN>
+// (gemm8p.hip): two tiles from one blocking fetch_add(2), tile i + 2 drawn at the start of tile i's epilogue, LDS mailbox, read at
+// k-tile 1 of tile i + 1 (the cursor crosses into the next tile in k-tile nk - 2: nk >= 3)
+template <int EPI, int XMODE, bool DYN = false>
 __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -101,18 +107,51 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
   const int tiles_n = (p.N + 255) >> 8;
   const int ntiles = tiles_m * tiles_n;
   const int G = gridDim.x, bx = blockIdx.x;
-  const int n_my = (ntiles - bx + G - 1) / G;
+  const int n_my = DYN ? 0x10000 : (ntiles - bx + G - 1) / G;
+  int q_start = 0, q_n = 0, d_cur = -1, d_next = -1;  // DYN: my queue's chunk of the tile list; tile computed / tile the cursor moves to next
+  bool d_more = DYN, d_mail = false, s_stop = false;
+  int* const d_head = DYN ? p.tq + (bx & 7) * 16 : nullptr;
+  int* const mbox = (int*)(smem + H8_RING);  // (the epilogue staging area is idle during the k loops)
+  auto pos_origin = [&](int wg, int& m0, int& n0) {
+    n0 = (wg % tiles_n) << 8;
+    m0 = (wg / tiles_n) << 7;
+  };
   auto tile_origin = [&](int i, int& m0, int& n0) {
     int wg = bx + i * G;
     if (p.xcd_swizzle & 1) {  // bijective on [0, ntiles): XCD x owns a contiguous chunk of the tile list
       const int q = ntiles >> 3, r = ntiles & 7, x = wg & 7;
       wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
     }
-    n0 = (wg % tiles_n) << 8;
-    m0 = (wg / tiles_n) << 7;
+    pos_origin(wg, m0, n0);
   };
+  auto tq_exit = [&]() {
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(p.tq + 128, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == G - 1) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) __hip_atomic_store(p.tq + 16 * x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.tq + 128, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if constexpr (DYN) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = bx & 7;
+    q_n = q + (x < r ? 1 : 0);
+    q_start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    if (tid == 0) *mbox = __hip_atomic_fetch_add(d_head, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int j = __builtin_amdgcn_readfirstlane(*(volatile int*)mbox);
+    __syncthreads();
+    if (j >= q_n) {
+      tq_exit();
+      return;
+    }
+    d_cur = q_start + j;
+    d_more = j + 1 < q_n;
+    d_next = d_more ? d_cur + 1 : -1;
+  }
   const int nk = (p.K + 63) >> 6;
-  const int H = n_my * nk * 3;  // slots this workgroup streams
+  const int H = n_my * nk * 3;  // slots this workgroup streams (DYN: unknown -- the cursor stops when a draw comes back empty)
 
   // ---------------------------------------------------------------- staging (LDS-DMA) side
   const char* zsrc = (const char*)g_zero_block;
@@ -176,7 +215,15 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
       if (++s_kt == nk) {
         s_kt = 0;
         s_pa = (const char*)p.A;
-        if (++s_i < n_my) {
+        if constexpr (DYN) {
+          if (d_next >= 0) {
+            int m0s, n0s;
+            pos_origin(d_next, m0s, n0s);
+            set_src(m0s, n0s);
+          } else {
+            s_stop = true;
+          }
+        } else if (++s_i < n_my) {
           int m0s, n0s;
           tile_origin(s_i, m0s, n0s);
           set_src(m0s, n0s);
@@ -194,11 +241,11 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
   // of the next k-tile's phase 0 B2 and B1 (8 pieces) are younger than the A needed.  Once the cursor has run dry (the last k-tile or
   // two of the workgroup): drain.
   auto wait_b2 = [&]() {
-    if (s_h < H) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (DYN ? !s_stop : s_h < H) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto wait_next_ktile = [&]() {
-    if (s_h < H) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (DYN ? !s_stop : s_h < H) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
@@ -237,14 +284,15 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
   // ---------------------------------------------------------------- prologue: B1(0), A(0), B2(0), B1(1) in flight, the first two landed
   {
     int m0s, n0s;
-    tile_origin(0, m0s, n0s);
+    if constexpr (DYN) pos_origin(d_cur, m0s, n0s);
+    else tile_origin(0, m0s, n0s);
     set_src(m0s, n0s);
     s_pb = s_pbt;
   }
-  if (s_h < H) issue(I0{});
-  if (s_h < H) issue(I1{});
-  if (s_h < H) issue(I2{});
-  if (s_h < H) issue(I0{});
+  if (DYN ? !s_stop : s_h < H) issue(I0{});
+  if (DYN ? !s_stop : s_h < H) issue(I1{});
+  if (DYN ? !s_stop : s_h < H) issue(I2{});
+  if (DYN ? !s_stop : s_h < H) issue(I0{});
   if (s_h >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B1(0), A(0) landed; B2(0), B1(1) in flight
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a one-k-tile stream (H = 3)
   phase_end();
@@ -252,8 +300,15 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
   int rot = 0;  // k-tiles computed so far (across my tiles) mod 3
   for (int ti = 0; ti < n_my; ++ti) {
     int m0, n0;
-    tile_origin(ti, m0, n0);
+    if constexpr (DYN) pos_origin(d_cur, m0, n0);
+    else tile_origin(ti, m0, n0);
     for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (DYN) {
+        if (kt == 1 && d_mail) {  // left by thread 0 at the end of the previous epilogue: every wave is >= 4 barriers past that
+          d_next = __builtin_amdgcn_readfirstlane(*(volatile int*)mbox);
+          d_more = d_next >= 0;
+        }
+      }
       const char* sb1 = smem + slot_of(0, rot);
       const char* sa = smem + slot_of(1, rot);
       const char* sb2 = smem + 2 * H8_SLOT;
@@ -270,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
       // ---- phase 1: B-second -> quadrant (cols 32..63, rows 0..63); A of the next k-tile goes where B-first was
       load_rows(sb2 + wave * 4096, b2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I1{});
+      if (DYN ? !s_stop : s_h < H) issue(I1{});
       __builtin_amdgcn_sched_barrier(0);
       mma2(acc[1][0], acc[1][1], b2, a1[0], a1[1]);
       phase_end();
@@ -278,12 +333,12 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
       load_rows(sa + 8192, a2[0]);
       load_rows(sa + 12288, a2[1]);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_h < H) issue(I2{});
+      if (DYN ? !s_stop : s_h < H) issue(I2{});
       __builtin_amdgcn_sched_barrier(0);
       mma2(acc[1][2], acc[1][3], b2, a2[0], a2[1]);
       phase_end();
       // ---- phase 3: quadrant (cols 0..31, rows 64..127); B-first of the k-tile after next goes where A was
-      if (s_h < H) issue(I0{});
+      if (DYN ? !s_stop : s_h < H) issue(I0{});
       __builtin_amdgcn_sched_barrier(0);
       mma2(acc[0][2], acc[0][3], b1, a2[0], a2[1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -293,9 +348,21 @@ __global__ __launch_bounds__(256, 2) void gemm8h_kernel(const GemmArgs p) {
     }
     char* reg = gemm_epilogue_uses_lds<EPI, false, 64, H8_REGION>(p) ? smem + H8_RING + wave * H8_REGION : nullptr;
     // (all four ring slots hold operands of the next k-tiles here: no second staging region for the SwiGLU epilogue)
+    int d_t = 0;
+    if constexpr (DYN) {  // the tile after next
+      if (d_more && tid == 0) d_t = __hip_atomic_fetch_add(d_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     gemm_epilogue<EPI, false, 128, 64, H8_REGION, XMODE>(p, acc, reg, m0, n0, 0, wave, lane, 0, nullptr);
     zero_acc();
+    if constexpr (DYN) {
+      d_mail = d_more;
+      if (d_more && tid == 0) *(volatile int*)mbox = d_t < q_n ? q_start + d_t : -1;
+      d_cur = d_next;
+      d_next = -1;
+      if (d_cur < 0) break;
+    }
   }
+  if constexpr (DYN) tq_exit();
 }
 
 template <int EPI, int XMODE = 0>
@@ -324,6 +391,20 @@ static int launch8h(const GemmArgs& a, hipStream_t s) {
     }
   }
   const int ntiles = cdiv(a.M, 128) * cdiv(a.N, 256);
+  if (ntiles > slots && a.K >= 192 && (a.xcd_swizzle & 1) && gemm_dyn_enabled()) {  // persistent launch: tiles drawn from the queues
+    if (int* tq = gemm_tile_queue(s)) {
+      auto dk = gemm8h_kernel<EPI, XMODE, true>;
+      static bool dattr = false;
+      if (!dattr) {
+        (void)hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS);
+        dattr = true;
+      }
+      GemmArgs b = a;
+      b.tq = tq;
+      hipLaunchKernelGGL(dk, dim3(slots), dim3(256), H8_LDS, s, b);
+      return check_launch("gemm8h_nt_dyn");
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(ntiles > slots ? slots : ntiles), dim3(256), H8_LDS, s, a);
   return check_launch("gemm8h_nt");
 }

@@ -714,7 +714,7 @@ static CombineScratch* combine_scratch(hipStream_t s) {
 // counter), zero between launches.  Launches on one stream are serialised and share a slot; every stream handle is bound to its own
 // slot the first time it is seen.  The pool (64 slots) is allocated at the first persistent launch outside stream capture (the trainers
 // warm up eagerly); no pool / no free slot: the launch keeps the static tile lists.
-static int* tile_queue(hipStream_t s) {
+int* gemm_tile_queue(hipStream_t s) {  // (shared with gemm8h.hip: launches on one stream are serialised, whatever the kernel)
   constexpr int SLOTS = 64;
   static std::mutex mu;
   static int* pool = nullptr;
@@ -743,7 +743,7 @@ static int* tile_queue(hipStream_t s) {
 // asked for (the trainers turn it on when they run beside collectives); default off -- on a chip the step has to itself the static
 // lists are 0.4 % faster (no draw at the start of a workgroup, no exit count: 702 vs 699 images/s, profiles/r06_dyn_tiles.log)
 static int g_dyn_mode = 0;
-static bool gemm_dyn_enabled() {
+bool gemm_dyn_enabled() {
   static int env = -2;
   if (env == -2) {
     const char* e = getenv("VTP_GEMM_DYN");
@@ -797,7 +797,7 @@ static int launch8p(const GemmArgs& a0, int splits, hipStream_t s) {
   if constexpr (!TRANS && EPI != EPI_F32_SLAB && EPI != EPI_F32_ATOMIC) {
     // persistent launch: tiles drawn from per-XCD queues (gemm8p_body DYN) when the shape allows the look-ahead (>= 4 k-tiles per tile)
     if (splits == 1 && ntiles > cap && a.K >= 256 && (a.xcd_swizzle & 1) && !a.timing && gemm_dyn_enabled()) {
-      int* tq = tile_queue(s);
+      int* tq = gemm_tile_queue(s);
       if (tq) {
         auto dk = gemm8p_dyn_kernel<EPI, VAR, XMODE>;
         static bool dattr = false;
