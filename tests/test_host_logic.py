@@ -569,8 +569,10 @@ def test_shipped_kernels_spill_ratchet():
     assert len(rows) > 150, f"only {len(rows)} kernels found in the built objects"
     worst = max(rows.items(), key=lambda kv: kv[1][0])
     assert worst[1][0] <= 64, f"{worst[0]} spills {worst[1][0]} VGPRs"
-    zero = ["vtp::gemm8h_kernel<0, 0>", "vtp::gemm8h_kernel<0, 1>", "vtp::gemm8h_kernel<0, 2>", "vtp::gemm8h_kernel<2, 0>",
-            "vtp::gemm4w_kernel<0, 0>", "vtp::attn_bwd_fused_kernel<8>", "vtp::attn_bwd_fused_kernel<2>", "vtp::attn_fwd_res2_kernel",
+    # (the third template argument of the half-size / one-wave kernels: false = static tile lists, the one-GPU default; true = tiles
+    # drawn from the queues, round 6)
+    zero = ["vtp::gemm8h_kernel<0, 0, false>", "vtp::gemm8h_kernel<0, 1, false>", "vtp::gemm8h_kernel<0, 2, false>", "vtp::gemm8h_kernel<2, 0, false>",
+            "vtp::gemm4w_kernel<0, 0, false>", "vtp::attn_bwd_fused_kernel<8>", "vtp::attn_bwd_fused_kernel<2>", "vtp::attn_fwd_res2_kernel",
             "vtp::gemm_nt_kernel<128, 64, 4, 1, 3, 0, false, false>", "vtp::gemm_nt_kernel<128, 64, 4, 1, 3, 1, false, false>",
             "vtp::adamw_ema_kernel", "vtp::prep_weights_kernel"]
     for k in zero:
@@ -580,8 +582,12 @@ def test_shipped_kernels_spill_ratchet():
             assert rows[n][0] == 0, f"{n}: {rows[n][0]} spilled VGPRs (was 0)"
     # epilogue-only spills of the 8-phase family and the one-wave kernels (tools/spill_report.py shows where): may shrink, not grow
     caps = {"vtp::gemm8p_kernel<0, false, 0, 0>": 4, "vtp::gemm8p_kernel<1, false, 0, 0>": 1, "vtp::gemm8p_kernel<2, false, 0, 0>": 4,
-            "vtp::gemm8p_kernel<0, false, 0, 1>": 33, "vtp::gemm8p_kernel<0, false, 0, 2>": 8, "vtp::gemm4w_grouped_tn_kernel": 64,
-            "vtp::gemm8p_grouped_tn_kernel": 4, "vtp::gemm4w_kernel<1, 0>": 18}
+            "vtp::gemm8p_kernel<0, false, 0, 1>": 33, "vtp::gemm8p_kernel<0, false, 0, 2>": 8, "vtp::gemm4w_grouped_tn_kernel": 48,
+            "vtp::gemm4w_grouped_tn_items_kernel": 48, "vtp::gemm8p_grouped_tn_kernel": 4, "vtp::gemm4w_kernel<1, 0, false>": 18,
+            # the queue-drawing variants (on beside collectives only): epilogue-side spills, none inside a k loop
+            "vtp::gemm8p_dyn_kernel<0, 0, 0>": 4, "vtp::gemm8p_dyn_kernel<1, 0, 0>": 12, "vtp::gemm8p_dyn_kernel<2, 0, 0>": 4,
+            "vtp::gemm8h_kernel<0, 0, true>": 4, "vtp::gemm8h_kernel<0, 1, true>": 4, "vtp::gemm8h_kernel<0, 2, true>": 8,
+            "vtp::gemm4w_kernel<0, 0, true>": 4}
     for k, cap in caps.items():
         hit = [n for n in rows if k in n]
         assert hit, f"kernel {k} not in the built objects"
