@@ -257,6 +257,7 @@ class Overlap:
     def __init__(self):
         self._sides = {}
         self._lane = 0
+        self._deferred = []
 
     @property
     def side(self):
@@ -271,8 +272,26 @@ class Overlap:
         self._side().wait_stream(torch.cuda.current_stream())
 
     def join(self):
+        self.run_deferred()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+
+    # Launch order inside a captured segment decides which hardware queue a kernel replays on: the HIP graph executor walks the
+    # segment's root nodes in capture order, hands each root the next queue and lets a node inherit the queue of the first
+    # predecessor that reaches it.  A side branch captured in FRONT of the main stream's first kernel therefore takes the main
+    # chain's join nodes onto its own queue, and the main chain pays a cross-queue signal (10-20 us of idle chip) on the way in and
+    # out of every such node.  Side work is therefore forked where its inputs are ready but ISSUED behind the main stream's next
+    # kernel: defer(fn) queues the issue, run_deferred() -- called by Stack.backward behind the first dgrad GEMM of a block, and by
+    # whoever joins -- performs it.  (VTP_FORK_LATE=0: issue at the fork, the order of rounds 2-5.)
+    def defer(self, fn):
+        if FORK_LATE:
+            self._deferred.append(fn)
+        else:
+            fn()
+
+    def run_deferred(self):
+        while self._deferred:
+            self._deferred.pop(0)()
 
     def lane(self, k: int):
         """context: fork / join / side refer to side stream k while a second tower is being issued on another stream"""
@@ -288,6 +307,7 @@ class Overlap:
         return ctx()
 
 
+FORK_LATE = _env_flag("VTP_FORK_LATE")
 OVERLAP = Overlap()
 # Decided by same-box A/B runs of rounds 1-3 and no longer switchable: apply_rope in the qkv GEMM's epilogue, the SwiGLU backward
 # in the w3 dgrad's epilogue, weight gradients as TN GEMMs straight from the activation layouts (no transposed copies, no fp32
@@ -903,12 +923,18 @@ class Stack:
         pending = None  # (block index, ops.WgradGroup) whose launch is due
 
         def launch_pending():
+            """fork now (the side stream picks up behind the norm backward that closed the previous block); the launch itself is
+            issued behind this block's first main-stream kernel (Overlap.defer)"""
             if pending is None:
                 return
             if OVERLAP.enabled and not WGRAD_INLINE:
                 OVERLAP.fork()
-                with torch.cuda.stream(OVERLAP.side):
-                    pending[1].launch()
+                side, grp = OVERLAP.side, pending[1]
+
+                def issue():
+                    with torch.cuda.stream(side):
+                        grp.launch()
+                OVERLAP.defer(issue)
             else:
                 pending[1].launch()
 
@@ -928,6 +954,7 @@ class Stack:
             linear_bwd(ws, "w3", b.w3, dy_b, hid, M, dpre if fused_act else dh,
                        bias_grad_done=dy_colsum_done if i == self.depth - 1 else self.w3_colsum_target(i) is not None,
                        ls=(b.ls2, b.gls2) if b.ls2 is not None else None, dgrad_swiglu=pre if fused_act else None, defer=probs)
+            OVERLAP.run_deferred()  # side work forked at the block boundary: behind the block's first main-stream kernel
             if vit:
                 if not fused_act:
                     ops.swiglu_bwd(dh, pre, dpre, M, H)

@@ -377,12 +377,12 @@ class VTPTrainer:
         self._hyper_ring = None
         self.use_graphs = use_graphs
         self._graphs = {}
-        # VTP_SINGLE_GRAPH=1 (experiment, off by default): without collectives nothing has to run BETWEEN graph segments, so the whole
-        # step can be captured as ONE hipGraph with the optimizer lane left forked across the bucket events (joined once, in front of
-        # the optimizer leg).  A kernel trace shows ~27 us of idle GPU at each of the 13 segment boundaries of a step, but the step
-        # time does not move (same box, 30 steps: 46.45 / 46.74 ms with segments, 46.69 / 46.86 ms as one graph): the boundaries'
-        # idle time is slack of the side streams, not of the critical path
-        self.single_graph = (not self.collectives) and os.environ.get("VTP_SINGLE_GRAPH", "0") in ("1", "true", "on")
+        # Without collectives nothing has to run BETWEEN graph segments: the whole step is captured as ONE hipGraph, the optimizer lane
+        # left forked across the bucket events and joined once, in front of the optimizer leg (VTP_SINGLE_GRAPH=0: one segment per
+        # bucket event, as with collectives).  Round 5 measured this at +-0 -- with the side branches captured in front of the main
+        # stream's kernels, which put every block's closing norm backward on the weight-gradient branch's queue (engine.Overlap.defer);
+        # with the main chain on one queue the segment boundaries are what is left between blocks: 44.72 -> 44.38 ms, same box
+        self.single_graph = (not self.collectives) and os.environ.get("VTP_SINGLE_GRAPH", "1") in ("1", "true", "on")
         if self.text is not None and (model.config.vision_clip_feat != "cls" or not model.config.vision_bottleneck_ae_only):
             self._clip_unsupported = ("the fused trainer implements the cls-token / un-bottlenecked CLIP image feature only "
                                       "(vision_clip_feat='cls', vision_bottleneck_ae_only=True); other settings train through "
@@ -628,6 +628,7 @@ class VTPTrainer:
         self._reduced_ranges = []
         self._head_keys = []
         self._opt_queue, self._opt_done, self._hooks_done = [], [], set()
+        del OVERLAP._deferred[:]  # (an aborted step must not leave an issue queued)
         self._opt_ema = ssl is not None
         lag = 2 if self.collectives else 1
         # the lane is joined in front of every event when an event ends a graph segment / launches a collective; with one graph per
@@ -706,12 +707,17 @@ class VTPTrainer:
         main = torch.cuda.current_stream()
         if self._opt_stream is None:
             self._opt_stream = torch.cuda.Stream()
-        self._opt_stream.wait_stream(main)
-        with torch.cuda.stream(self._opt_stream):
-            self._opt_update(keys)
+        OVERLAP.run_deferred()
+        self._opt_stream.wait_stream(main)  # the lane picks up here ...
+
+        def issue():  # ... and its kernels are issued behind the main stream's next kernel (engine.Overlap.defer: queue placement)
+            with torch.cuda.stream(self._opt_stream):
+                self._opt_update(keys)
+        OVERLAP.defer(issue)
         self._opt_busy = True
 
     def _opt_join(self):
+        OVERLAP.run_deferred()
         if self._opt_busy:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._opt_busy = False
