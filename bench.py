@@ -13,8 +13,9 @@ One "step" = one full optimizer step of the hot path on one batch of synthetic 2
 config.workload says exactly what ran.  Rank 0 prints ONE JSON line.
 
 Inside the timed region, EVERY step draws fresh block-wise iBOT masks (vtp_amd.data.collate_ssl_masks, host numpy), builds
-the SSL index plan (VTPTrainer.prepare_ssl) and copies it to the device: the captured hipGraph is keyed by the padded
-masked-token buffer size (the collate's `upperbound`, vtp.py:432-439) and serves every draw.  The image / caption / crop
+the SSL index plan (VTPTrainer.prepare_ssl) and copies it to the device -- one batch ahead of the step that consumes it, as a
+prefetching loader does (the draw for step k + 1 is issued while the GPU runs step k; K timed steps = K draws): the captured
+hipGraph is keyed by the padded masked-token buffer size (the collate's `upperbound`, vtp.py:432-439) and serves every draw.  The image / caption / crop
 tensors stay resident in HBM (the contract's "inputs already resident").  `lpips_on` repeats the measurement (fewer steps) with
 the perceptual term of north_star switched on.
 
@@ -426,25 +427,35 @@ def main():
     img_rec = torch.randn(B, 3, res, res, device=dev, generator=torch.Generator(device=dev).manual_seed(4242 + rank))
     state["separate"] = False  # True: the reconstruction objective sees its own tensor -> its own trunk pass (reference accounting)
 
-    def one_step(trainer, txt):
-        """the step as a training loop runs it: fresh masks -> index plan -> H2D -> optimizer step"""
-        ssl = None
+    def draw_batch(trainer):
+        """fresh masks -> index plan -> pinned pack -> H2D enqueue: what a loader worker + collate does for one batch"""
         t0 = time.perf_counter()
+        masks, upper = mask_stream.draw()
+        t1 = time.perf_counter()
+        ssl = trainer.prepare_ssl(crops[0], crops[1], masks, upperbound=upper)
+        state["n_masked"].append(ssl["plan"]["n_masked"])
+        state["Ts"].add(ssl["plan"]["Ts"])
+        state["last_plan"] = ssl["plan"]
+        t2 = time.perf_counter()
+        wait_s, trainer._stager.wait_s = trainer._stager.wait_s, 0.0
+        host_t[0] += t1 - t0
+        host_t[1] += t2 - t1 - wait_s
+        host_t[3] += wait_s
+        return ssl
+
+    def one_step(trainer, txt):
+        """the step as a training loop with a prefetching loader runs it: the optimizer step on the batch drawn during the previous
+        step, then the draw of the next batch (fresh masks -> index plan -> H2D) while the GPU runs this one.  Every step draws exactly
+        one batch; the first timed step consumes the batch drawn by the last warm-up step, the last timed step draws one that the next
+        step would consume."""
+        ssl = None
         if do_ssl:
-            masks, upper = mask_stream.draw()
-            t1 = time.perf_counter()
-            ssl = trainer.prepare_ssl(crops[0], crops[1], masks, upperbound=upper)
-            state["n_masked"].append(ssl["plan"]["n_masked"])
-            state["Ts"].add(ssl["plan"]["Ts"])
-            state["last_plan"] = ssl["plan"]
-            t2 = time.perf_counter()
-            wait_s, trainer._stager.wait_s = trainer._stager.wait_s, 0.0
-            host_t[0] += t1 - t0
-            host_t[1] += t2 - t1 - wait_s
-            host_t[3] += wait_s
-            t0 = t2
+            ssl = state.pop("next_ssl", None) or draw_batch(trainer)
+        t0 = time.perf_counter()
         out = trainer.step(img, txt, ssl, reconstruction_image=img_rec if state["separate"] else None)
         host_t[2] += time.perf_counter() - t0
+        if do_ssl:
+            state["next_ssl"] = draw_batch(trainer)
         return out
 
     def sync():
@@ -454,8 +465,9 @@ def main():
 
     def measure(perceptual_weight: float, steps: int, warmup: int, separate: bool = False):
         state["separate"] = separate
-        launch = "eager" if args.no_graphs else "hipGraph segments"
+        state.pop("next_ssl", None)
         model, lp, trainer, txt = build_trainer(not args.no_graphs, perceptual_weight)
+        launch = "eager" if args.no_graphs else ("one hipGraph per step" if trainer.single_graph else "hipGraph segments (collectives between them)")
         try:
             for _ in range(warmup):
                 one_step(trainer, txt)
@@ -702,7 +714,7 @@ def main():
         gflop_img += ssl_trunk + head
         gflop_ref += ssl_trunk + head
         nm = state["n_masked"]
-        ssl_info = {"prototypes": dh["K"], "masks": "fresh block-wise iBOT masks every step (host collate + index plan + H2D inside the timed region)",
+        ssl_info = {"prototypes": dh["K"], "masks": "fresh block-wise iBOT masks every step (host collate + index plan + H2D inside the timed region, one batch ahead of the step that consumes it: a prefetching loader)",
                     "masked_tokens_min_mean_max": [min(nm), round(sum(nm) / len(nm), 1), max(nm)], "masked_token_buffer_rows": pl["Tm"],
                     "graph_keys_seen": len(state["Ts"]), "student_head_rows": pl["Ts"],
                     "global_crops": 2, "local_crops": 8, "local_res": 96, "ssl_loss": round(ssl_loss_val, 4)}
