@@ -10,8 +10,9 @@ loss, optimizer or DDP wrapper.  This module is that missing d
     xGMI is point-to-point, so few large messages beat many small ones;
   * the contrastive head exchanges L2-normalised image/text features with one all-gather each and returns the
     cross-rank feature gradients with one reduce-scatter each (OpenCLIP local_loss + gather_with_grad semantics);
-  * the whole step is captured once as a short chain of hipGraph segments (collectives stay between segments) and
-    replayed; hyper-parameters live in device memory so the replay sees per-step values;
+  * the whole step is captured once and replayed -- as ONE hipGraph without collectives, as a short chain of segments with the
+    collectives between them otherwise; side work is issued behind the main stream's next kernel so that the main chain replays on
+    one hardware queue (engine.Overlap.defer); hyper-parameters live in device memory so the replay sees per-step values;
   * one fused AdamW launch per contiguous parameter range + one batched bf16-weight refresh launch.
 
 Objectives (OUR spec -- the reference defines no loss; parity unpinned):
