@@ -631,3 +631,26 @@ def test_wgrad_group_item_list_partitions_every_tile():
             # planned for fewer CUs (VTP_GEMM_CUS = 240 beside RCCL's channels): 241 workgroups no longer fit one round -> the uniform cut
             items2, slots2 = wgrad_group_items(rs, Ktok, base, cus=240)
             assert (slots2, len(items2)) == (2, 216)
+
+
+def test_overlap_defer_issues_in_order_behind_the_next_main_kernel(monkeypatch):
+    """engine.Overlap.defer: forked side work is queued and issued -- in fork order, exactly once -- by the next run_deferred() (what
+    Stack.backward calls behind a block's first dgrad GEMM) or by a join; VTP_FORK_LATE=0 issues at the fork"""
+    from vtp_amd import engine
+    ov = engine.Overlap()
+    log = []
+    monkeypatch.setattr(engine, "FORK_LATE", True)
+    ov.defer(lambda: log.append("lane"))
+    ov.defer(lambda: log.append("wgrad"))
+    assert log == []
+    log.append("dgrad")          # the main stream's kernel goes first
+    ov.run_deferred()
+    assert log == ["dgrad", "lane", "wgrad"]
+    ov.run_deferred()
+    assert log == ["dgrad", "lane", "wgrad"]   # nothing is issued twice
+    ov.defer(lambda: log.append("late"))
+    ov.join()                    # a join may not leave a fork un-issued (no side stream yet: nothing to wait for)
+    assert log[-1] == "late" and ov._deferred == []
+    monkeypatch.setattr(engine, "FORK_LATE", False)
+    ov.defer(lambda: log.append("now"))
+    assert log[-1] == "now" and ov._deferred == []
