@@ -166,6 +166,24 @@ def test_ssl_kernels_vs_torch():
     ref_dxb[:, 1:][masks.bool()] = 0
     o.mask_rows_bwd(dx, dxb, masks, dm, B, N, D)
     assert relF(dm, ref_dm) < 1e-6 and torch.equal(dxb.view(B, N, D), ref_dxb)
+    # the benchmark step's launch: 64 global crops x 257 tokens x 768 (65 rows per workgroup, a ragged last one)
+    B, N, D = 64, 257, 768
+    dx = torch.randn(B * N, D, device=DEV, generator=g)
+    dxb = bf(dx)
+    masks = (torch.rand(B, N - 1, device=DEV, generator=g) < 0.15).to(torch.uint8)
+    dm = torch.zeros(D, device=DEV)
+    ref_dm = dx.view(B, N, D)[:, 1:][masks.bool()].double().sum(0).float()
+    ref_dxb = dxb.clone().view(B, N, D)
+    ref_dxb[:, 1:][masks.bool()] = 0
+    o.mask_rows_bwd(dx, dxb, masks, dm, B, N, D)
+    assert relF(dm, ref_dm) < 1e-5 and torch.equal(dxb.view(B, N, D), ref_dxb)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        o.mask_rows_bwd(dx, dxb, masks, dm, B, N, D)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"TOOLS mask_rows_bwd 64 x 257 x 768: {e0.elapsed_time(e1) * 50:.1f} us per launch")
 
 
 def test_ssl_forward_vs_reference_legacy_class(sslg):

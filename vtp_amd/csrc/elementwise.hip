@@ -556,31 +556,57 @@ __global__ __launch_bounds__(256) void strided_rowsum_kernel(const float* __rest
 }
 
 // backward of the mask-token substitution (vision_transformer.py:195): rows whose patch embedding was replaced by
-// mask_token send their gradient to mask_token and nothing to the patch embedding.  One workgroup per 16 token rows,
-// thread = feature columns; per-block partial sums -> one atomic per column per block.
+// mask_token send their gradient to mask_token and nothing to the patch embedding.  One workgroup per `rpb` <= 256 consecutive token
+// rows, one wave per quarter of them: lane l reads the mask byte of the wave's l-th row, a ballot gives the masked rows, and only those
+// are read -- 64 lanes x 16 column chunks in flight per row -- and zeroed in the bf16 copy; the four waves' sums meet in LDS, one atomic
+// per column and workgroup.  (Until round 6: one thread per column scanning 16 rows, 1 028 workgroups x 768 atomics on the same 768
+// addresses -- 95 us for the 64 x 257 global crops of the benchmark step.)
 __global__ __launch_bounds__(256) void mask_rows_bwd_kernel(const float* __restrict__ dx, bf16* __restrict__ dxb,
                                                             const unsigned char* __restrict__ masks, float* __restrict__ d_mask,
-                                                            int B, int N, int D) {
+                                                            int B, int N, int D, int rpb) {
+  extern __shared__ float part[];  // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long rows = (long)B * N;
-  const long r0 = (long)blockIdx.x * 16;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float s = 0.f;
-    bool any = false;
-    for (int i = 0; i < 16; ++i) {
-      const long r = r0 + i;
-      if (r >= rows) break;
+  const int rpw = (rpb + 3) >> 2;  // <= 64
+  const long w0 = (long)blockIdx.x * rpb + (long)wave * rpw;
+  long w1 = w0 + rpw;
+  const long b1 = (long)(blockIdx.x + 1) * rpb;
+  if (w1 > b1) w1 = b1;
+  if (w1 > rows) w1 = rows;
+  bool flag = false;
+  {
+    const long r = w0 + lane;
+    if (r < w1) {
       const int n = (int)(r % N);
-      if (n == 0) continue;
-      const long b = r / N;
-      if (masks[b * (N - 1) + (n - 1)]) {
-        const long o = r * D + d;
-        s += dx[o];
-        dxb[o] = (bf16)0.f;
-        any = true;
+      flag = n != 0 && masks[(r / N) * (N - 1) + (n - 1)] != 0;
+    }
+  }
+  const unsigned long long hit = __ballot(flag);
+  for (int d0 = 0; d0 < D; d0 += 1024) {
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    unsigned long long m = hit;
+    while (m) {
+      const int i = __builtin_ctzll(m);
+      m &= m - 1;
+      const long o = (w0 + i) * D + d0 + lane;
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) v[c] = (d0 + c * 64 + lane < D) ? dx[o + c * 64] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc[c] += v[c];
+        if (d0 + c * 64 + lane < D) dxb[o + c * 64] = (bf16)0.f;
       }
     }
-    if (any) unsafeAtomicAdd(d_mask + d, s);
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (d0 + c * 64 + lane < D) part[wave * D + d0 + c * 64 + lane] = acc[c];
   }
+  __syncthreads();
+  if (__syncthreads_or(hit != 0ull))
+    for (int d = threadIdx.x; d < D; d += 256) unsafeAtomicAdd(d_mask + d, (part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d]));
 }
 
 static inline int grid_for(long items, int cap = 4096) {
@@ -661,8 +687,13 @@ extern "C" int vtp_colsum_bf16_rows(const void* in, int ld, float* out, const in
 extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,
                                  int D, void* stream) {
   VTP_REQUIRE(dx && dx_bf16 && masks && d_mask_token && B > 0 && N > 1 && D > 0, "vtp_mask_rows_bwd: bad argument");
-  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv((long)B * N, 16)), dim3(256), 0, (hipStream_t)stream, dx, (bf16*)dx_bf16, masks,
-                     d_mask_token, B, N, D);
+  VTP_REQUIRE(D <= 8192, "vtp_mask_rows_bwd: D > 8192");
+  const long rows = (long)B * N;
+  long rpb = cdiv(rows, 512L);  // <= 512 workgroups x D atomics; a wave handles at most 64 rows
+  if (rpb < 16) rpb = 16;
+  if (rpb > 256) rpb = 256;
+  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv(rows, rpb)), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream, dx,
+                     (bf16*)dx_bf16, masks, d_mask_token, B, N, D, (int)rpb);
   return check_launch("mask_rows_bwd");
 }
 
