@@ -170,6 +170,10 @@ int vtp_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
 /* im2col for the 16x16/s16 patch-embed conv (embeddings.py:58,64-69): img f32 [B,3,H,W] -> patches bf16 [B*h*w, 768],
  * K order (c, ky, kx), token order (y, x). */
 int vtp_im2col16(const float* img, void* patches, int B, int H, int W, void* stream);
+/* the same into a row layout with `prefix` rows in front of every image's patches (prefix = 1: the trunk's token rows, row 0 = cls, cf.
+ * prepare_tokens_with_masks, vision_transformer.py:189-219): patch p of image b -> row b*(h*w+prefix) + prefix + p of rows bf16
+ * [B*(h*w+prefix), 768]; the prefix rows are not written */
+int vtp_im2col16_rows(const float* img, void* rows, int B, int H, int W, int prefix, void* stream);
 /* gradient w.r.t. the input image of PatchEmbed (embeddings.py:61-70 backward; the reference's autograd returns it when the image
  * requires grad): d_patches f32 [B*hw, 768] (= d_tokens[patch rows] W_pe, K order (c, ky, kx)) folded back to d_img f32 [B,3,H,W] */
 int vtp_col2im16(const float* dpatches, float* dimg, int B, int H, int W, void* stream);
@@ -196,6 +200,11 @@ int vtp_colsum_bf16_rows(const void* in, int ld, float* out, const int* n_rows_d
 int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N, int D,
                       void* stream);
 /* out[d] += sum_b in[b*stride + d], f32 (gradient of the broadcast cls token, vision_transformer.py:210-217). */
+/* backward of vtp_assemble_tokens as a whole (vision_transformer.py:189-219 backward): the mask substitution as above (masks and
+ * d_mask_token may both be null: an item without masks) AND the cls row: d_cls_token += dx[row 0 of every image], dx_bf16[row 0] = 0 --
+ * afterwards dx_bf16 is the gradient of the patch-embed output in the token-row layout (zero in every row that is not a visible patch) */
+int vtp_token_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, float* d_cls_token, int B, int N,
+                       int D, void* stream);
 int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream);
 
 /* f32 -> bf16 cast (n elements); f32 [R,C] -> bf16 transposed [C,R] (weight caches W, W^T). */

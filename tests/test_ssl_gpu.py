@@ -184,6 +184,24 @@ def test_ssl_kernels_vs_torch():
     e1.record()
     torch.cuda.synchronize()
     print(f"TOOLS mask_rows_bwd 64 x 257 x 768: {e0.elapsed_time(e1) * 50:.1f} us per launch")
+    # the whole token-assembly backward: masked rows AND the cls row (with and without masks), im2col into token rows
+    for use_masks in (True, False):
+        dxb = bf(dx)
+        dm, dc = torch.zeros(D, device=DEV), torch.full((D,), 2.0, device=DEV)
+        ref_dxb = dxb.clone().view(B, N, D)
+        ref_dxb[:, 0] = 0
+        if use_masks:
+            ref_dxb[:, 1:][masks.bool()] = 0
+        o.token_rows_bwd(dx, dxb, masks if use_masks else None, dm if use_masks else None, dc, B, N, D)
+        assert torch.equal(dxb.view(B, N, D), ref_dxb)
+        assert relF(dc, 2.0 + dx.view(B, N, D)[:, 0].double().sum(0).float()) < 1e-5
+        assert relF(dm, ref_dm) < 1e-5 if use_masks else float(dm.abs().max()) == 0.0
+    img = torch.randn(3, 3, 32, 48, device=DEV, generator=g)
+    pt = torch.empty(3 * 6, 768, dtype=torch.bfloat16, device=DEV)
+    rows = torch.full((3 * 7, 768), 7.0, dtype=torch.bfloat16, device=DEV)
+    o.im2col16(img, pt, 3, 32, 48)
+    o.im2col16_rows(img, rows, 3, 32, 48, 1)
+    assert torch.equal(rows.view(3, 7, 768)[:, 1:], pt.view(3, 6, 768)) and float((rows.view(3, 7, 768)[:, 0].float() - 7.0).abs().max()) == 0.0
 
 
 def test_ssl_forward_vs_reference_legacy_class(sslg):

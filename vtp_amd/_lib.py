@@ -18,11 +18,13 @@ SIGNATURES = {
     "vtp_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],
     "vtp_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _F, _I, _P],
     "vtp_im2col16": [_P, _P, _I, _I, _I, _P],
+    "vtp_im2col16_rows": [_P, _P, _I, _I, _I, _I, _P],
     "vtp_col2im16": [_P, _P, _I, _I, _I, _P],
     "vtp_assemble_tokens": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_transpose_bf16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],  # in ld out ld colsum swiglu_h in_grp in_pre R C stream
     "vtp_strided_rowsum": [_P, _L, _P, _I, _I, _P],
     "vtp_mask_rows_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vtp_token_rows_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vtp_cast_f32_bf16": [_P, _P, _L, _P],
     "vtp_cast_transpose_f32_bf16": [_P, _P, _I, _I, _P],
     "vtp_prep_weights": [_P, _I, _I, _P],

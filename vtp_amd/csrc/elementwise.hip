@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(bf16* __restrict__ qkv, co
 
 // ---------------------------------------------------------------- im2col for the k=s=16 patch-embed conv
 // work item = (token, c, ky): 16 contiguous pixels -> 16 bf16 at K offset c*256 + ky*16.
+// pre: patch p of image b goes to row b * (h w + pre) + pre + p -- pre = 1 is the token layout of the trunk (row 0 of an image = cls)
 __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__ img, bf16* __restrict__ patches,
-                                                       int B, int H, int W) {
+                                                       int B, int H, int W, int pre) {
   const int h = H / 16, w = W / 16;
   const long total = (long)B * h * w * 48;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__
     const int y = (int)((tok / w) % h);
     const long b = tok / ((long)w * h);
     const float* src = img + ((b * 3 + c) * H + (y * 16 + ky)) * (long)W + x * 16;
-    bf16* dst = patches + tok * 768 + c * 256 + ky * 16;
+    bf16* dst = patches + (tok + (b + 1) * pre) * 768 + c * 256 + ky * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = *(const f32x4*)(src + 4 * i);
@@ -555,16 +556,17 @@ __global__ __launch_bounds__(256) void strided_rowsum_kernel(const float* __rest
   if (wave == 0 && d < D) out[d] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// backward of the mask-token substitution (vision_transformer.py:195): rows whose patch embedding was replaced by
-// mask_token send their gradient to mask_token and nothing to the patch embedding.  One workgroup per `rpb` <= 256 consecutive token
-// rows, one wave per quarter of them: lane l reads the mask byte of the wave's l-th row, a ballot gives the masked rows, and only those
-// are read -- 64 lanes x 16 column chunks in flight per row -- and zeroed in the bf16 copy; the four waves' sums meet in LDS, one atomic
-// per column and workgroup.  (Until round 6: one thread per column scanning 16 rows, 1 028 workgroups x 768 atomics on the same 768
-// addresses -- 95 us for the 64 x 257 global crops of the benchmark step.)
-__global__ __launch_bounds__(256) void mask_rows_bwd_kernel(const float* __restrict__ dx, bf16* __restrict__ dxb,
-                                                            const unsigned char* __restrict__ masks, float* __restrict__ d_mask,
-                                                            int B, int N, int D, int rpb) {
-  extern __shared__ float part[];  // [4][D]
+// backward of the token assembly (vision_transformer.py:189-219): rows whose patch embedding was replaced by mask_token send their
+// gradient to mask_token and nothing to the patch embedding; with d_cls, row 0 of every image sends its gradient to cls_token (and is
+// zeroed in the bf16 copy as well: what remains there is exactly the gradient of the patch-embed OUTPUT in the token-row layout).
+// One workgroup per `rpb` <= 256 consecutive token rows, one wave per quarter of them: lane l reads the kind of the wave's l-th row, two
+// ballots give the masked / cls rows, and only those are read -- 64 lanes x 16 column chunks in flight per row; the four waves' sums meet
+// in LDS, one atomic per column, target and workgroup.  (Until round 6: one thread per column scanning 16 rows, 1 028 workgroups x 768
+// atomics on the same 768 addresses -- 95 us for the 64 x 257 global crops of the benchmark step -- and a separate row-0 sum.)
+__global__ __launch_bounds__(256) void token_rows_bwd_kernel(const float* __restrict__ dx, bf16* __restrict__ dxb,
+                                                             const unsigned char* __restrict__ masks, float* __restrict__ d_mask,
+                                                             float* __restrict__ d_cls, int B, int N, int D, int rpb) {
+  extern __shared__ float part[];  // [2][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long rows = (long)B * N;
   const int rpw = (rpb + 3) >> 2;  // <= 64
@@ -573,40 +575,50 @@ __global__ __launch_bounds__(256) void mask_rows_bwd_kernel(const float* __restr
   const long b1 = (long)(blockIdx.x + 1) * rpb;
   if (w1 > b1) w1 = b1;
   if (w1 > rows) w1 = rows;
-  bool flag = false;
+  bool f_mask = false, f_cls = false;
   {
     const long r = w0 + lane;
     if (r < w1) {
       const int n = (int)(r % N);
-      flag = n != 0 && masks[(r / N) * (N - 1) + (n - 1)] != 0;
+      f_cls = d_cls != nullptr && n == 0;
+      f_mask = masks != nullptr && n != 0 && masks[(r / N) * (N - 1) + (n - 1)] != 0;
     }
   }
-  const unsigned long long hit = __ballot(flag);
-  for (int d0 = 0; d0 < D; d0 += 1024) {
-    float acc[16];
+  const unsigned long long hit[2] = {__ballot(f_mask), __ballot(f_cls)};
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    unsigned long long m = hit;
-    while (m) {
-      const int i = __builtin_ctzll(m);
-      m &= m - 1;
-      const long o = (w0 + i) * D + d0 + lane;
-      float v[16];
+  for (int k = 0; k < 2; ++k) {
+    float* out = part + (size_t)k * 4 * D + (size_t)wave * D;
+    for (int d0 = 0; d0 < D; d0 += 1024) {
+      float acc[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = (d0 + c * 64 + lane < D) ? dx[o + c * 64] : 0.f;
+      for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+      unsigned long long m = hit[k];
+      while (m) {
+        const int i = __builtin_ctzll(m);
+        m &= m - 1;
+        const long o = (w0 + i) * D + d0 + lane;
+        float v[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        acc[c] += v[c];
-        if (d0 + c * 64 + lane < D) dxb[o + c * 64] = (bf16)0.f;
+        for (int c = 0; c < 16; ++c) v[c] = (d0 + c * 64 + lane < D) ? dx[o + c * 64] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          acc[c] += v[c];
+          if (d0 + c * 64 + lane < D) dxb[o + c * 64] = (bf16)0.f;
+        }
       }
-    }
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (d0 + c * 64 + lane < D) part[wave * D + d0 + c * 64 + lane] = acc[c];
+      for (int c = 0; c < 16; ++c)
+        if (d0 + c * 64 + lane < D) out[d0 + c * 64 + lane] = acc[c];
+    }
   }
   __syncthreads();
-  if (__syncthreads_or(hit != 0ull))
+  const bool any_mask = __syncthreads_or(hit[0] != 0ull), any_cls = __syncthreads_or(hit[1] != 0ull);
+  if (any_mask)
     for (int d = threadIdx.x; d < D; d += 256) unsafeAtomicAdd(d_mask + d, (part[d] + part[D + d]) + (part[2 * D + d] + part[3 * D + d]));
+  if (any_cls) {
+    const float* pc = part + (size_t)4 * D;
+    for (int d = threadIdx.x; d < D; d += 256) unsafeAtomicAdd(d_cls + d, (pc[d] + pc[D + d]) + (pc[2 * D + d] + pc[3 * D + d]));
+  }
 }
 
 static inline int grid_for(long items, int cap = 4096) {
@@ -637,8 +649,16 @@ extern "C" int vtp_im2col16(const float* img, void* patches, int B, int H, int W
   VTP_REQUIRE(img && patches, "vtp_im2col16: null pointer");
   VTP_REQUIRE(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "vtp_im2col16: H and W must be positive multiples of 16");
   const long items = (long)B * (H / 16) * (W / 16) * 48;
-  hipLaunchKernelGGL(im2col16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, B, H, W);
+  hipLaunchKernelGGL(im2col16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)patches, B, H, W, 0);
   return check_launch("im2col16");
+}
+
+extern "C" int vtp_im2col16_rows(const float* img, void* rows, int B, int H, int W, int prefix, void* stream) {
+  VTP_REQUIRE(img && rows, "vtp_im2col16_rows: null pointer");
+  VTP_REQUIRE(B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && prefix >= 0, "vtp_im2col16_rows: H and W must be positive multiples of 16, prefix >= 0");
+  const long items = (long)B * (H / 16) * (W / 16) * 48;
+  hipLaunchKernelGGL(im2col16_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)rows, B, H, W, prefix);
+  return check_launch("im2col16_rows");
 }
 
 extern "C" int vtp_col2im16(const float* dpatches, float* dimg, int B, int H, int W, void* stream) {
@@ -684,17 +704,28 @@ extern "C" int vtp_colsum_bf16_rows(const void* in, int ld, float* out, const in
   return check_launch("colsum_bf16_rows");
 }
 
-extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,
-                                 int D, void* stream) {
-  VTP_REQUIRE(dx && dx_bf16 && masks && d_mask_token && B > 0 && N > 1 && D > 0, "vtp_mask_rows_bwd: bad argument");
-  VTP_REQUIRE(D <= 8192, "vtp_mask_rows_bwd: D > 8192");
+static int launch_token_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, float* d_cls_token,
+                                 int B, int N, int D, void* stream, const char* what) {
   const long rows = (long)B * N;
-  long rpb = cdiv(rows, 512L);  // <= 512 workgroups x D atomics; a wave handles at most 64 rows
+  long rpb = cdiv(rows, 512L);  // <= 512 workgroups x D atomics per target; a wave handles at most 64 rows
   if (rpb < 16) rpb = 16;
   if (rpb > 256) rpb = 256;
-  hipLaunchKernelGGL(mask_rows_bwd_kernel, dim3(cdiv(rows, rpb)), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream, dx,
-                     (bf16*)dx_bf16, masks, d_mask_token, B, N, D, (int)rpb);
-  return check_launch("mask_rows_bwd");
+  hipLaunchKernelGGL(token_rows_bwd_kernel, dim3(cdiv(rows, rpb)), dim3(256), (size_t)8 * D * sizeof(float), (hipStream_t)stream, dx,
+                     (bf16*)dx_bf16, masks, d_mask_token, d_cls_token, B, N, D, (int)rpb);
+  return check_launch(what);
+}
+
+extern "C" int vtp_mask_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, int B, int N,
+                                 int D, void* stream) {
+  VTP_REQUIRE(dx && dx_bf16 && masks && d_mask_token && B > 0 && N > 1 && D > 0 && D <= 2048, "vtp_mask_rows_bwd: bad argument (D <= 2048)");
+  return launch_token_rows_bwd(dx, dx_bf16, masks, d_mask_token, nullptr, B, N, D, stream, "mask_rows_bwd");
+}
+
+extern "C" int vtp_token_rows_bwd(const float* dx, void* dx_bf16, const unsigned char* masks, float* d_mask_token, float* d_cls_token,
+                                  int B, int N, int D, void* stream) {
+  VTP_REQUIRE(dx && dx_bf16 && d_cls_token && (masks == nullptr) == (d_mask_token == nullptr) && B > 0 && N > 1 && D > 0 && D <= 2048,
+              "vtp_token_rows_bwd: bad argument (masks and d_mask_token together or neither; D <= 2048)");
+  return launch_token_rows_bwd(dx, dx_bf16, masks, d_mask_token, d_cls_token, B, N, D, stream, "token_rows_bwd");
 }
 
 extern "C" int vtp_strided_rowsum(const float* in, long stride, float* out, int B, int D, void* stream) {

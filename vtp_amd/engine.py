@@ -308,6 +308,8 @@ class Overlap:
 
 
 FORK_LATE = _env_flag("VTP_FORK_LATE")
+# VTP_PE_IN_GROUP=0: the patch-embed weight gradient as its own split-K launches (one set per list item) behind block 0's group
+PE_IN_GROUP = _env_flag("VTP_PE_IN_GROUP")
 OVERLAP = Overlap()
 # Decided by same-box A/B runs of rounds 1-3 and no longer switchable: apply_rope in the qkv GEMM's epilogue, the SwiGLU backward
 # in the w3 dgrad's epilogue, weight gradients as TN GEMMs straight from the activation layouts (no transposed copies, no fp32
@@ -895,9 +897,16 @@ class Stack:
         return b.w3.gb if (b.ls2 is None and self.drop_plan is None) else None
 
     # dy: f32 [M,D] grad of the stack output, dy_b: its bf16 copy.  Returns (dx f32, dx bf16) for the stack input.
+    def dx_buffers(self, ws: Workspace, M: int):
+        """(f32, bf16) buffers backward() returns the stack-input gradient in (block 0's outputs; static like every workspace buffer)"""
+        return ws.get("b.dx0", (M, self.D), F32), ws.get("b.dx_b0", (M, self.D), BF)
+
     def backward(self, ws: Workspace, dy, dy_b, B: int, N: int, rope, prefix_tokens: int, saved=None, segs=None,
-                 dy_colsum_done: bool = False):
-        """Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
+                 dy_colsum_done: bool = False, hold_last: bool = False, extra_last=None):
+        """hold_last (grouped weight gradients only): block 0's group is neither launched nor announced here but left in self.held =
+        (0, group) -- the caller launches it and yields ("block", 0) -- and extra_last, a list of linear_bwd-style problem records over the
+        same token rows (TrunkEngine: the patch-embed weight gradient, whose dy is this stack's input gradient), rides in that launch.
+        Generator: yields ("block", i) each time all parameter gradients of block i have been enqueued (a
         gradient-bucket / graph-segment boundary for the trainer); returns (dx f32, dx bf16) of the stack input.
         dy_colsum_done: the caller's norm backward already summed dy_b's columns into the last block's w3 bias gradient
         (self.blocks[-1].w3.gb as its dx_colsum)."""
@@ -990,17 +999,22 @@ class Stack:
                 OVERLAP.join()
                 yield ("block", i)
                 continue
-            gkey = (i, bool(self.wgrad_overwrite))
+            extra = extra_last if (i == 0 and hold_last and extra_last) else []
+            gkey = (i, bool(self.wgrad_overwrite), len(extra))
             grp = groups.get(gkey)
             if grp is None:
                 grp = ops.WgradGroup(M)
-                for pr in probs:
+                for pr in probs + list(extra):
                     grp.add(pr["dy"], pr["x"], pr["gw"], pr["gb"], pr["N"], pr["K"], pr["swiglu_h"], accumulate=not self.wgrad_overwrite)
                 groups[gkey] = grp.finalize(self.store.device, scratch)
             if pending is not None:
                 yield ("block", pending[0])  # its weight gradients are complete (joined above)
             pending = (i, grp)
-        if pending is not None:  # block 0's group: nothing of this stack is left to run beside it
+        self.held = None
+        if pending is not None and hold_last:
+            OVERLAP.run_deferred()
+            self.held = pending
+        elif pending is not None:  # block 0's group: nothing of this stack is left to run beside it
             pending[1].launch()
             yield ("block", pending[0])
         return dy, dy_b
@@ -1233,12 +1247,15 @@ class TrunkEngine:
             for g in segs:
                 g.rope = RopeAugTabs(rec["sin"], rec["cos"], off, g.hw)
                 off += g.hw
-        patches = ws.get("patches", (P, 768), BF)
+        # im2col rows in the TOKEN layout (row 0 of every image is never written and stays zero): the patch-embed weight gradient is then
+        # one product over the same rows as the blocks' weight gradients -- d_tokens^T patches with the cls rows contributing zero -- and
+        # rides in block 0's grouped launch (backward()) instead of three few-tile split-K launches at the end of the step
+        patches = ws.get("patches_tok", (M, 768), BF, zero=True)
         x0 = ws.get("x0", (M, D), F32)
         for g in segs:
-            pt, xs = patches[g.prow0:g.prow0 + g.B * g.hw], x0[g.row0:g.row0 + g.B * g.N]
-            ops.im2col16(g.img, pt, g.B, g.h * 16, g.w * 16)
-            ops.gemm_nt(pt, self.pe.w, xs, M=g.B * g.hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, c_remap=(g.hw, 1))
+            pt, xs = patches[g.row0:g.row0 + g.B * g.N], x0[g.row0:g.row0 + g.B * g.N]
+            ops.im2col16_rows(g.img, pt, g.B, g.h * 16, g.w * 16, 1)
+            ops.gemm_nt(pt, self.pe.w, xs, M=g.B * g.hw, N=D, K=768, bias=self.pe.bias, epi=EPI_F32, a_remap=(g.hw, 1), c_remap=(g.hw, 1))
             ops.assemble_tokens(xs, st.p(self.prefix + "cls_token"), st.p(self.prefix + "mask_token"), g.masks, g.B, g.N, D)
         stack_segs = [(g.B, g.N, g.rope) for g in segs]
         dropped = train and self.stack.drop_plan is not None
@@ -1300,27 +1317,42 @@ class TrunkEngine:
                      dx_colsum=self.stack.w3_colsum_target(self.depth - 1))
         OVERLAP.join()
         yield "tail"
+        g_cls, g_mask = st.g(self.prefix + "cls_token"), st.g(self.prefix + "mask_token")
         if getattr(c, "dropped", False):
             dx0 = yield from self.stack.backward_drop(ws, dx, c.stack_segs, 1, c.stack_saved)
             dx0_b = dx_b
             ops.cast_f32_bf16(dx0, dx0_b, M * D)
+            self.stack.held = None
         else:
+            # the patch-embed weight (and bias) gradient as a fifth problem of block 0's grouped launch: dy = the stack's input gradient
+            # (cls and masked rows zeroed by token_rows_bwd below, before the launch), x = the im2col rows in the token layout
+            extra = None
+            if PE_IN_GROUP and not want_dimg and D % 8 == 0:
+                extra = [dict(dy=self.stack.dx_buffers(ws, M)[1], x=c.patches, gw=self.pe.gw, gb=self.pe.gb, N=self.pe.N, K=self.pe.K, swiglu_h=0)]
             dx0, dx0_b = yield from self.stack.backward(ws, dx, dx_b, 0, 0, None, 1, c.stack_saved, segs=c.stack_segs,
-                                                        dy_colsum_done=self.stack.w3_colsum_target(self.depth - 1) is not None)
-        for item, g in enumerate(c.segs):
+                                                        dy_colsum_done=self.stack.w3_colsum_target(self.depth - 1) is not None,
+                                                        hold_last=extra is not None, extra_last=extra)
+        held, self.stack.held = getattr(self.stack, "held", None), None
+        # backward of the token assembly (vision_transformer.py:189-219): masked rows -> mask_token, row 0 -> cls_token, both zeroed in the
+        # bf16 copy (what is left there is the gradient of the patch-embed output, in token rows)
+        for g in c.segs:
             d_s, d_sb = dx0[g.row0:g.row0 + g.B * g.N], dx0_b[g.row0:g.row0 + g.B * g.N]
-            if g.masks is not None:  # masked rows carried mask_token, not a patch embedding (vision_transformer.py:195)
-                ops.mask_rows_bwd(d_s, d_sb, g.masks, st.g(self.prefix + "mask_token"), g.B, g.N, D)
-            # patch embed: dW += dx0[patch rows]^T patches ; cls token: sum over the batch of row 0
-            linear_bwd(ws, "pe", self.pe, d_sb, c.patches[g.prow0:g.prow0 + g.B * g.hw], g.B * g.hw, None, need_dx=False,
-                       dy_remap=(g.hw, 1))
-            ops.strided_rowsum(d_s, g.N * D, st.g(self.prefix + "cls_token"), g.B, D)
-            if want_dimg:
-                dpt = ws.get(f"b.dpatch{g.prow0}", (g.B * g.hw, 768), F32)
-                ops.gemm_nt(d_sb, self.pe.wT, dpt, M=g.B * g.hw, N=768, K=D, epi=EPI_F32, a_remap=(g.hw, 1))
-                dimg = torch.empty(g.B, 3, g.h * 16, g.w * 16, dtype=F32, device=st.device)
-                ops.col2im16(dpt, dimg, g.B, g.h * 16, g.w * 16)
-                c.__dict__.setdefault("d_img", {})[item] = dimg
+            ops.token_rows_bwd(d_s, d_sb, g.masks, g_mask if g.masks is not None else None, g_cls, g.B, g.N, D)
+        if held is not None:
+            assert dx0_b.data_ptr() == self.stack.dx_buffers(ws, M)[1].data_ptr()
+            held[1].launch()
+            yield ("block", held[0])
+        else:
+            for item, g in enumerate(c.segs):  # patch embed: dW += d_tokens[patch rows]^T patches, one launch sequence per item
+                d_sb = dx0_b[g.row0:g.row0 + g.B * g.N]
+                linear_bwd(ws, "pe", self.pe, d_sb, c.patches[g.row0:g.row0 + g.B * g.N], g.B * g.hw, None, need_dx=False,
+                           dy_remap=(g.hw, 1), x_remap=(g.hw, 1))
+                if want_dimg:
+                    dpt = ws.get(f"b.dpatch{g.prow0}", (g.B * g.hw, 768), F32)
+                    ops.gemm_nt(d_sb, self.pe.wT, dpt, M=g.B * g.hw, N=768, K=D, epi=EPI_F32, a_remap=(g.hw, 1))
+                    dimg = torch.empty(g.B, 3, g.h * 16, g.w * 16, dtype=F32, device=st.device)
+                    ops.col2im16(dpt, dimg, g.B, g.h * 16, g.w * 16)
+                    c.__dict__.setdefault("d_img", {})[item] = dimg
         OVERLAP.join()
 
 

@@ -79,6 +79,11 @@ def im2col16(img, patches, B, H, W):
     _lib.check(_lib_().vtp_im2col16(_p(img), _p(patches), B, H, W, _s()), "vtp_im2col16")
 
 
+def im2col16_rows(img, rows, B, H, W, prefix=1):
+    """patch p of image b -> row b * (hw + prefix) + prefix + p of rows bf16 [B * (hw + prefix), 768] (prefix rows untouched)"""
+    _lib.check(_lib_().vtp_im2col16_rows(_p(img), _p(rows), B, H, W, prefix, _s()), "vtp_im2col16_rows")
+
+
 def col2im16(dpatches, dimg, B, H, W):
     """d_img f32 [B,3,H,W] <- d_patches f32 [B*hw, 768] (inverse of im2col16: the PatchEmbed input gradient)"""
     _lib.check(_lib_().vtp_col2im16(_p(dpatches), _p(dimg), B, H, W, _s()), "vtp_col2im16")
@@ -95,6 +100,13 @@ def transpose_bf16(inp, ld_in, out, ld_out, R, C, colsum=None, swiglu_h=0, in_re
 
 def strided_rowsum(inp, stride, out, B, D):
     _lib.check(_lib_().vtp_strided_rowsum(_p(inp), stride, _p(out), B, D, _s()), "vtp_strided_rowsum")
+
+
+def token_rows_bwd(dx, dxb, masks, d_mask_token, d_cls_token, B, N, D):
+    """backward of assemble_tokens: masked rows -> d_mask_token (masks may be None), row 0 of every image -> d_cls_token; both kinds of
+    row zeroed in the bf16 copy"""
+    _lib.check(_lib_().vtp_token_rows_bwd(_p(dx), _p(dxb), _p(masks), None if masks is None else _p(d_mask_token), _p(d_cls_token), B, N, D,
+                                          _s()), "vtp_token_rows_bwd")
 
 
 def mask_rows_bwd(dx, dxb, masks, d_mask_token, B, N, D):
