@@ -189,6 +189,9 @@ class HostStager:
         for k, a, o in plan:
             t = d[o:o + a.nbytes]
             out[k] = t.view(_NP2TORCH[a.dtype.name]).view(a.shape)
+        # the packed device buffer itself and where each array sits in it: a consumer that keeps STATIC copies of the arrays (the
+        # hipGraph driver) refreshes all of them with one device copy when the layouts agree
+        out["_packed"] = (d, tuple((k, o, a.nbytes, a.dtype.name, tuple(a.shape)) for k, a, o in plan))
         return out
 
 
@@ -615,7 +618,8 @@ class VTPTrainer:
         arrays["masks"] = m.astype(np.uint8)
         up = self._stager.upload(arrays)
         masks_dev = up.pop("masks")
-        return dict(**{"global": global_crops, "local": local_crops}, masks=masks_dev, plan=plan, dev=up)
+        packed = up.pop("_packed")
+        return dict(**{"global": global_crops, "local": local_crops}, masks=masks_dev, plan=plan, dev=up, packed=packed)
 
     def _step_gen(self, images: torch.Tensor, text: Optional[torch.Tensor], ssl: Optional[dict] = None, rec_images=None):
         """_step_body plus (a) the bookkeeping of which flat ranges have been handed to the gradient exchange so far (known at
@@ -1208,7 +1212,15 @@ class VTPTrainer:
             static_txt = None if text is None else text.clone()
             static_ssl = None
             if ssl is not None:  # static copies of every per-step SSL input (crops, masks, index tensors)
-                static_ssl = dict(plan=ssl["plan"], masks=ssl["masks"].clone(), dev={k: v.clone() for k, v in ssl["dev"].items()})
+                if ssl.get("packed") is not None:
+                    # prepare_ssl's arrays arrive as views of ONE packed upload: the static copies are views of one static buffer with the
+                    # same layout, refreshed by one device copy per step instead of ten
+                    buf, layout = ssl["packed"]
+                    sbuf = buf.clone()
+                    views = {k: sbuf[o:o + nb].view(_NP2TORCH[dt]).view(shp) for k, o, nb, dt, shp in layout}
+                    static_ssl = dict(plan=ssl["plan"], masks=views.pop("masks"), dev=views, packed=(sbuf, layout))
+                else:
+                    static_ssl = dict(plan=ssl["plan"], masks=ssl["masks"].clone(), dev={k: v.clone() for k, v in ssl["dev"].items()})
                 static_ssl["global"], static_ssl["local"] = ssl["global"].clone(), ssl["local"].clone()
             snap = (st.flat_p.clone(), self.m.clone(), self.v.clone())
             if ssl is not None:
@@ -1269,9 +1281,13 @@ class VTPTrainer:
         if ssl is not None:
             static_ssl["global"].copy_(ssl["global"])
             static_ssl["local"].copy_(ssl["local"])
-            static_ssl["masks"].copy_(ssl["masks"])
-            for k, v in ssl["dev"].items():
-                static_ssl["dev"][k].copy_(v)
+            sp, pk = static_ssl.get("packed"), ssl.get("packed")
+            if sp is not None and pk is not None and sp[1] == pk[1]:
+                sp[0].copy_(pk[0])
+            else:
+                static_ssl["masks"].copy_(ssl["masks"])
+                for k, v in ssl["dev"].items():
+                    static_ssl["dev"][k].copy_(v)
         for g, ev in segs:
             g.replay()
             if ev is not None:
