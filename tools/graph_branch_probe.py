@@ -147,6 +147,8 @@ def contention_probe():
                 main.wait_stream(A)
         return g
 
+    for ns in (50, 100, 200):
+        print(f"  40 big + {ns} small: {time_graph(cap(40, ns)) * 1e3:.0f} us (small alone {time_graph(cap(0, ns)) * 1e3:.0f})")
     tm, ts = time_graph(cap(40, 0)), time_graph(cap(0, 400))
     tb = time_graph(cap(40, 400))
     tp = time_graph(cap(40, 400, side_prio=-1))
