@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: does the text-tower backward run beside the decoder backward in the replayed step?  One traced step per setting; prints the
+# round 6: where the text-tower backward sits relative to the decoder backward in a TRACED step -- NOT evidence of what the untraced replay
+# does: rocprofv3 serialises kernel chains on different queues (profiles/r06_text_backward_trace_artifact.txt).  One traced step per setting; prints the
 # start of the first / last causal attention backward (text) and of the decoder's first / last fused attention backward
 export PYTHONDONTWRITEBYTECODE=1
 R=$PWD
